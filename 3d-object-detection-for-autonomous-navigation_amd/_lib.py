@@ -1,0 +1,138 @@
+"""ctypes binding of the C-ABI in include/pp_hip.h (libpp_hip.so, built in-tree by hipcc).
+
+There is no CPU fallback: if the shared library is missing or cannot be
+loaded, `lib()` raises, and every compute entry point needs a gfx950 device
+(`pp_create` fails without one).  `build()` only needs hipcc (it cross-compiles
+for gfx950 on a machine without a GPU).
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+_INCLUDE = os.path.join(os.path.dirname(_PKG), "include", "pp_hip.h")
+SO_PATH = os.path.join(_PKG, "libpp_hip.so")
+SOURCES = ["pp_api.hip", "voxelize.hip", "pfn.hip", "anchor_mask.hip", "backbone.hip", "postprocess.hip"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
+               "-Wall", "-Wno-unused-function"]
+
+EXPORTS = [
+    "pp_abi_version", "pp_create", "pp_destroy", "pp_last_error", "pp_set_weight", "pp_finalize_weights",
+    "pp_set_anchors", "pp_points_to_voxel", "pp_anchor_mask", "pp_forward_voxels", "pp_predict",
+    "pp_upload_points", "pp_upload_points_device", "pp_set_calib", "pp_detect_async", "pp_sync",
+    "pp_get_detections", "pp_detect", "pp_fetch_intermediates", "pp_set_profiling", "pp_get_kernel_times",
+    "pp_timer_start", "pp_timer_stop", "pp_device_info",
+]
+
+
+class PPConfig(ctypes.Structure):
+    _fields_ = [
+        ("pc_range", ctypes.c_double * 6),
+        ("voxel_size", ctypes.c_double * 3),
+        ("max_points", ctypes.c_int32),
+        ("max_voxels", ctypes.c_int32),
+        ("num_point_features", ctypes.c_int32),
+        ("pfn_filters", ctypes.c_int32),
+        ("layer_nums", ctypes.c_int32 * 3),
+        ("layer_strides", ctypes.c_int32 * 3),
+        ("num_filters", ctypes.c_int32 * 3),
+        ("upsample_strides", ctypes.c_int32 * 3),
+        ("num_upsample_filters", ctypes.c_int32 * 3),
+        ("num_anchor_per_loc", ctypes.c_int32),
+        ("num_class", ctypes.c_int32),
+        ("nms_pre_max_size", ctypes.c_int32),
+        ("nms_post_max_size", ctypes.c_int32),
+        ("nms_score_threshold", ctypes.c_float),
+        ("nms_iou_threshold", ctypes.c_float),
+        ("anchor_area_threshold", ctypes.c_float),
+        ("max_batch", ctypes.c_int32),
+        ("max_points_per_frame", ctypes.c_int32),
+    ]
+
+
+class PPDetection(ctypes.Structure):
+    _fields_ = [
+        ("box3d_camera", ctypes.c_double * 7),
+        ("box3d_lidar", ctypes.c_float * 7),
+        ("score", ctypes.c_float),
+        ("label", ctypes.c_int32),
+        ("dir_label", ctypes.c_int32),
+        ("anchor_index", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libpp_hip.so")
+
+
+def needs_build():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(_CSRC, "pp_common.h"), _INCLUDE]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compiles every HIP source for gfx950 into <package>/libpp_hip.so."""
+    if not force and not needs_build():
+        return SO_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", SO_PATH] + [os.path.join(_CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Loads libpp_hip.so (raises if absent -- the HIP path is the only path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.")
+    L = ctypes.CDLL(SO_PATH)
+    vp, i32, i64, f32p = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    L.pp_abi_version.restype = ctypes.c_int
+    L.pp_create.argtypes = [ctypes.POINTER(PPConfig), ctypes.c_int, ctypes.POINTER(vp)]
+    L.pp_destroy.argtypes = [vp]
+    L.pp_last_error.argtypes = [vp]
+    L.pp_last_error.restype = ctypes.c_char_p
+    L.pp_set_weight.argtypes = [vp, ctypes.c_char_p, f32p, ctypes.POINTER(i64), i32]
+    L.pp_finalize_weights.argtypes = [vp]
+    L.pp_set_anchors.argtypes = [vp, f32p, vp, i64]
+    L.pp_points_to_voxel.argtypes = [vp, f32p, i64, f32p, vp, vp, ctypes.POINTER(i32)]
+    L.pp_anchor_mask.argtypes = [vp, vp, i64, i32, vp]
+    L.pp_forward_voxels.argtypes = [vp, f32p, vp, vp, i64, i32, f32p, f32p, f32p, f32p, f32p]
+    L.pp_predict.argtypes = [vp, f32p, f32p, f32p, vp, f32p, f32p, i32, vp, vp]
+    L.pp_upload_points.argtypes = [vp, f32p, vp, i32]
+    L.pp_upload_points_device.argtypes = [vp, vp, vp, i32]
+    L.pp_set_calib.argtypes = [vp, f32p, f32p, i32]
+    L.pp_detect_async.argtypes = [vp]
+    L.pp_sync.argtypes = [vp]
+    L.pp_get_detections.argtypes = [vp, vp, vp]
+    L.pp_detect.argtypes = [vp, f32p, vp, i32, f32p, f32p, vp, vp]
+    L.pp_fetch_intermediates.argtypes = [vp, vp, vp, vp, vp, f32p, f32p, f32p, f32p]
+    L.pp_set_profiling.argtypes = [vp, i32]
+    L.pp_get_kernel_times.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
+                                      ctypes.POINTER(i32)]
+    L.pp_timer_start.argtypes = [vp]
+    L.pp_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.pp_device_info.argtypes = [vp, ctypes.c_char_p, i32, ctypes.POINTER(i32), ctypes.POINTER(i64)]
+    for name in EXPORTS:
+        fn = getattr(L, name)  # raises AttributeError if the symbol is not exported
+        if name not in ("pp_last_error",):
+            fn.restype = ctypes.c_int
+    _lib = L
+    return L

@@ -1,0 +1,79 @@
+// Per-frame anchor mask: pillar occupancy -> 2-D inclusive prefix sum -> 4 lookups per anchor.
+//
+// Replaces, per frame (reference load_data.py:3043-3072):
+//   sparse_sum_for_anchors_mask (:586-591)  occupancy[y][x] += 1 per pillar (both z-cells count)
+//   .cumsum(0).cumsum(1)        (:3054-3055)
+//   fused_get_anchors_area      (:558-584)  area = D - B - C + A at the anchor's clamped cells
+//   anchors_mask = area > anchor_area_threshold (:3070)
+// The anchor -> cell mapping (rbbox2d_to_near_bbox + float64 floor + clamp) is
+// static and precomputed on the host (anchors.py); the occupancy comes for free
+// from the voxeliser's cell -> pillar map.  Counts are kept in int32 (the
+// reference's float32 counts are exact integers).  HBM/L2-bound integer work:
+// 4*nz bytes read + 4 bytes written per cell, 16 B + 4 gathers + 1 B per anchor.
+#include "pp_common.h"
+
+__global__ __launch_bounds__(256) void k_occ_rowscan(const int* __restrict__ cellmap, int rows, int nz, int ny,
+                                                     int nx, int* __restrict__ integ) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / ny, y = row - b * ny;
+    const size_t plane = (size_t)ny * nx;
+    const int* map = cellmap + (size_t)b * nz * plane + (size_t)y * nx;
+    int* out = integ + (size_t)b * plane + (size_t)y * nx;
+    int carry = 0;
+    for (int x0 = 0; x0 < nx; x0 += 64) {
+        const int x = x0 + lane;
+        int v = 0;
+        if (x < nx)
+            for (int z = 0; z < nz; ++z) v += (map[(size_t)z * plane + x] >= 0) ? 1 : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (x < nx) out[x] = carry + incl;
+        carry += __shfl(incl, 63);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_colscan(int* __restrict__ integ, int batch, int ny, int nx) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= batch * nx) return;
+    const int b = t / nx, x = t - b * nx;
+    int* col = integ + (size_t)b * ny * nx + x;
+    int run = 0;
+    int y = 0;
+    for (; y + 8 <= ny; y += 8) {
+        int v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = col[(size_t)(y + q) * nx];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { run += v[q]; col[(size_t)(y + q) * nx] = run; }
+    }
+    for (; y < ny; ++y) { run += col[(size_t)y * nx]; col[(size_t)y * nx] = run; }
+}
+
+__global__ __launch_bounds__(256) void k_anchor_lookup(const int* __restrict__ integ,
+                                                       const int* __restrict__ cells, int64_t A, int ny, int nx,
+                                                       float threshold, uint8_t* __restrict__ mask) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= A) return;
+    const int b = blockIdx.y;
+    const int4 c = reinterpret_cast<const int4*>(cells)[a];  // x0 y0 x1 y1
+    const int* I = integ + (size_t)b * ny * nx;
+    const int area = I[(size_t)c.w * nx + c.z] - I[(size_t)c.w * nx + c.x] - I[(size_t)c.y * nx + c.z] +
+                     I[(size_t)c.y * nx + c.x];
+    mask[(size_t)b * A + a] = ((float)area > threshold) ? 1 : 0;
+}
+
+void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, const int* cells, int64_t A,
+                        float threshold, int* integ, uint8_t* mask, hipStream_t s) {
+    if (batch <= 0) return;
+    const int rows = batch * ny;
+    hipLaunchKernelGGL(k_occ_rowscan, dim3((rows + 3) / 4), dim3(256), 0, s, cellmap, rows, nz, ny, nx, integ);
+    hipLaunchKernelGGL(k_colscan, dim3((batch * nx + 255) / 256), dim3(256), 0, s, integ, batch, ny, nx);
+    hipLaunchKernelGGL(k_anchor_lookup, dim3((unsigned)((A + 255) / 256), batch), dim3(256), 0, s, integ, cells, A,
+                       ny, nx, threshold, mask);
+}

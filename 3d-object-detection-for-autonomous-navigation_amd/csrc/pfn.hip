@@ -1,0 +1,207 @@
+// Fused PillarFeatureNet + PointPillarsScatter, canvas-cell centric.
+//
+// Replaces PillarFeatureNet.call (reference model/pointpillars.py:128-225) and
+// PointPillarsScatter.call (:285-341), and the NCHW->NHWC transpose the RPN does
+// first (model/voxelnet.py:697):
+//   mean over the pillar's points; features [raw F | xyz - mean | xy - pillar centre];
+//   rows >= num_points masked to zero; Dense(Fa->C, no bias) -> BN(eps 1e-3) -> ReLU;
+//   max over ALL T rows (a pillar with fewer than T points also maxes with the
+//   padded-row constant ReLU(beta - gamma*mean/sqrt(var+eps)));
+//   scatter to canvas[y*nx + x], pillars of different z-cells that share (y, x)
+//   are SUMMED (tf.scatter_nd semantics).
+// BatchNorm is folded into the dense kernel / bias at weight-finalise time.
+//
+// Mapping: every canvas cell is written exactly once -- zeros when no pillar
+// maps to it, otherwise the sum over its z-cells -- so there is no memset, no
+// atomics and the result is bit-reproducible.  One wavefront owns 16
+// consecutive cells of a frame: lanes own channels (C/64 per lane; the Fa x C
+// weights live in VGPRs), the pillar's points are loaded one per lane
+// (coalesced through the CSR index list) and broadcast with v_readlane, the
+// per-pillar max is a running register max.  HBM-bound: reads 4F bytes per
+// point + the cell map, writes 4C bytes per canvas cell.
+#include "pp_common.h"
+
+template <int N>
+struct FVec { float v[N]; };
+
+__device__ __forceinline__ float bcast(float x, int srclane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), srclane));
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+template <int CPL, int F, bool PADDED>
+__global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
+    constexpr int FA = F + 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int ncanvas = p.ny * p.nx;
+    const int cell0 = (blockIdx.x * 4 + wave) * 16;
+    if (cell0 >= ncanvas) return;
+    const int ncells = min(16, ncanvas - cell0);
+    const int C = p.C;
+    const int ch0 = lane * CPL;
+    const bool ch_ok = ch0 < C;
+
+    // weights for this lane's channels
+    float w[FA][CPL], bias[CPL];
+#pragma unroll
+    for (int k = 0; k < FA; ++k)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) w[k][q] = ch_ok ? p.w[k * C + ch0 + q] : 0.f;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) bias[q] = ch_ok ? p.bias[ch0 + q] : 0.f;
+
+    const int* map = p.cellmap + (size_t)b * p.nz * ncanvas;
+    unsigned occ = 0;
+    for (int z = 0; z < p.nz; ++z) {
+        const int v = (lane < ncells) ? map[(size_t)z * ncanvas + cell0 + lane] : -1;
+        occ |= (unsigned)(__ballot(v >= 0) & 0xffffull);
+    }
+
+    float* cbase = p.canvas + ((size_t)b * ncanvas + cell0) * C;
+    // zero-fill the cells no pillar maps to (16-byte stores, one cell per C/4 lanes)
+    {
+        const int nq = ncells * C / 4;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = lane; q < nq; q += 64) {
+            const int c = (q * 4) / C;
+            if (!((occ >> c) & 1u)) reinterpret_cast<float4*>(cbase)[q] = z4;
+        }
+    }
+
+    const int n0 = PADDED ? 0 : p.offsets[b];
+    const int* ps = PADDED ? nullptr : p.pillar_start + (size_t)b * (p.max_voxels + 1);
+    const int T = p.T;
+
+    while (occ) {
+        const int c = __builtin_ctz(occ);
+        occ &= occ - 1;
+        const int cell = cell0 + c;
+        const int yi = cell / p.nx, xi = cell - yi * p.nx;
+        // pillar centre: float(idx) * v + offset, two float32 roundings (model/pointpillars.py:156-171)
+        const float cxf = __fadd_rn(__fmul_rn((float)xi, p.vx), p.x_off);
+        const float cyf = __fadd_rn(__fmul_rn((float)yi, p.vy), p.y_off);
+        float acc[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
+
+        for (int z = 0; z < p.nz; ++z) {
+            // wave-uniform (every lane loads the same word); make that visible to the compiler
+            const int pid = __builtin_amdgcn_readfirstlane(map[(size_t)z * ncanvas + cell]);
+            if (pid < 0) continue;
+            int n, nsum;
+            const float* src;           // PADDED: rows of this pillar
+            const unsigned* sidx = nullptr;
+            if (PADDED) {
+                n = __builtin_amdgcn_readfirstlane(min(max(p.num_points[pid], 0), T));
+                nsum = T;               // the reference sums all T rows (model/pointpillars.py:143)
+                src = p.voxels + (size_t)pid * T * F;
+            } else {
+                const int start = __builtin_amdgcn_readfirstlane(ps[pid]);
+                n = __builtin_amdgcn_readfirstlane(min(ps[pid + 1] - start, T));
+                nsum = n;
+                sidx = p.sorted_idx + n0 + start;
+                src = p.pts + (size_t)n0 * F;
+            }
+            // ---- mean over the pillar ----
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int j0 = 0; j0 < nsum; j0 += 64) {
+                const int j = j0 + lane;
+                if (j < nsum) {
+                    const float* q = PADDED ? (src + (size_t)j * F) : (src + (size_t)sidx[j] * F);
+                    sx += q[0]; sy += q[1]; sz += q[2];
+                }
+            }
+            sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+            const float fn = (float)n;
+            const float mx = sx / fn, my = sy / fn, mz = sz / fn;
+
+            // ---- per point: features -> dense -> (folded BN) -> ReLU -> running max ----
+            float m[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) m[q] = 0.f;
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                const int j = j0 + lane;
+                float pt[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) pt[f] = 0.f;
+                if (j < n) {
+                    const float* q = PADDED ? (src + (size_t)j * F) : (src + (size_t)sidx[j] * F);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) pt[f] = q[f];
+                }
+                const int cnt = min(64, n - j0);
+                for (int jj = 0; jj < cnt; ++jj) {
+                    float ft[FA];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) ft[f] = bcast(pt[f], jj);
+                    ft[F + 0] = ft[0] - mx;
+                    ft[F + 1] = ft[1] - my;
+                    ft[F + 2] = ft[2] - mz;
+                    ft[F + 3] = ft[0] - cxf;
+                    ft[F + 4] = ft[1] - cyf;
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) {
+                        float o = bias[q];
+#pragma unroll
+                        for (int k = 0; k < FA; ++k) o = fmaf(ft[k], w[k][q], o);
+                        m[q] = fmaxf(m[q], fmaxf(o, 0.f));
+                    }
+                }
+            }
+            if (n < T) {  // zero-padded rows: Dense(0) = 0 -> BN shift -> ReLU
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) m[q] = fmaxf(m[q], fmaxf(bias[q], 0.f));
+            }
+            if (p.feat_out != nullptr && ch_ok) {
+                const size_t row = PADDED ? (size_t)pid : ((size_t)b * p.max_voxels + pid);
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) p.feat_out[row * C + ch0 + q] = m[q];
+            }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) acc[q] += m[q];
+        }
+        if (ch_ok) {
+            float* dst = cbase + (size_t)c * C + ch0;
+            if constexpr (CPL == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else if constexpr (CPL == 2) {
+                *reinterpret_cast<float2*>(dst) = make_float2(acc[0], acc[1]);
+            } else {
+                dst[0] = acc[0];
+            }
+        }
+    }
+}
+
+template <int CPL, int F>
+static void launch_pfn_t(const PfnParams& p, bool padded, hipStream_t s) {
+    const int ncanvas = p.ny * p.nx;
+    dim3 grid((ncanvas + 63) / 64, p.batch);
+    if (padded)
+        hipLaunchKernelGGL((k_pfn_canvas<CPL, F, true>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((k_pfn_canvas<CPL, F, false>), grid, dim3(256), 0, s, p);
+}
+
+int launch_pfn(const PfnParams& p, bool padded, hipStream_t s) {
+    if (p.batch <= 0) return 0;
+    const int C = p.C;
+    int cpl;
+    if (C <= 64) cpl = 1;
+    else if (C == 128) cpl = 2;
+    else if (C == 256) cpl = 4;
+    else return PP_ERR_UNSUPPORTED;
+    if (C % 4 != 0) return PP_ERR_UNSUPPORTED;
+    if (p.F != 3 && p.F != 4) return PP_ERR_UNSUPPORTED;
+#define PFN_CASE(CPLV, FV) \
+    if (cpl == CPLV && p.F == FV) { launch_pfn_t<CPLV, FV>(p, padded, s); return 0; }
+    PFN_CASE(1, 3) PFN_CASE(1, 4) PFN_CASE(2, 3) PFN_CASE(2, 4) PFN_CASE(4, 3) PFN_CASE(4, 4)
+#undef PFN_CASE
+    return PP_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,866 @@
+// C-ABI of libpp_hip.so (include/pp_hip.h): engine lifetime, weight folding, device
+// workspaces, the stage pipelines and the measurement hooks.  Host side only; the
+// kernels live in voxelize.hip / pfn.hip / anchor_mask.hip / backbone.hip /
+// postprocess.hip.  Everything runs on one HIP stream owned by the handle.
+#include <math.h>
+#include <algorithm>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "pp_common.h"
+
+namespace {
+
+std::string g_create_error;
+
+struct KTime { const char* name; int ev; };
+
+}  // namespace
+
+struct pp_engine {
+    pp_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    VoxGeom geom;
+    int nx = 0, ny = 0, nz = 0, ncell = 0;
+    int head_h = 0, head_w = 0, napl = 0;
+    int64_t A = 0;
+    int C = 0, F = 0, T = 0, FA = 0, CC = 0;
+    int B = 0, NMAX = 0;
+
+    std::map<std::string, std::vector<float>> hw;
+    std::map<std::string, std::vector<int64_t>> hshape;
+    bool weights_ready = false, anchors_ready = false;
+    std::vector<void*> allocs;
+
+    float* d_points = nullptr;
+    int* d_offsets = nullptr;
+    int* d_cell = nullptr;
+    int* d_first = nullptr;
+    int* d_cellmap = nullptr;
+    unsigned *d_keyA = nullptr, *d_idxA = nullptr, *d_keyB = nullptr, *d_idxB = nullptr;
+    int* d_pstart = nullptr;
+    int* d_pcell = nullptr;
+    int* d_npillars = nullptr;
+    int* d_nvalid = nullptr;
+    float *d_pfn_w = nullptr, *d_pfn_b = nullptr;
+    float* d_canvas = nullptr;
+    float* d_act[2] = {nullptr, nullptr};
+    float* d_concat = nullptr;
+    float *d_box = nullptr, *d_cls = nullptr, *d_dir = nullptr;
+    int* d_integ = nullptr;
+    uint8_t* d_mask = nullptr;
+    float* d_anchors = nullptr;
+    int* d_cells = nullptr;
+    float* d_calib = nullptr;
+    pp_detection* d_dets = nullptr;
+    int* d_ndets = nullptr;
+    pp_detection* h_dets = nullptr;  // pinned
+    int* h_ndets = nullptr;          // pinned
+    std::vector<LayerDesc> layers;
+
+    // compat scratch (grow-only)
+    float* d_voxels = nullptr; size_t cap_voxels = 0;
+    int* d_numpts = nullptr;   size_t cap_numpts = 0;
+    int* d_coors = nullptr;    size_t cap_coors = 0;
+    float* d_feat = nullptr;   size_t cap_feat = 0;
+
+    int cur_batch = 0, cur_max_n = 0;
+    std::vector<int> h_offsets;
+
+    int prof = 0;
+    std::vector<hipEvent_t> events;
+    std::vector<KTime> ktimes;
+    int ev_used = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+namespace {
+
+int fail(pp_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                              \
+    do {                                                                                             \
+        hipError_t _st = (call);                                                                     \
+        if (_st != hipSuccess)                                                                       \
+            return fail(e, PP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_st), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename Tp>
+int dalloc(pp_engine* e, Tp** p, size_t count) {
+    void* q = nullptr;
+    size_t bytes = count * sizeof(Tp);
+    if (bytes == 0) bytes = sizeof(Tp);
+    HIPCHK(e, hipMalloc(&q, bytes));
+    e->allocs.push_back(q);
+    *p = (Tp*)q;
+    return PP_OK;
+}
+
+template <typename Tp>
+int dgrow(pp_engine* e, Tp** p, size_t* cap, size_t count) {
+    if (count <= *cap && *p) return PP_OK;
+    if (*p) { (void)hipStreamSynchronize(e->stream); (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    void* q = nullptr;
+    HIPCHK(e, hipMalloc(&q, (count ? count : 1) * sizeof(Tp)));
+    *p = (Tp*)q;
+    *cap = count;
+    return PP_OK;
+}
+
+// ---- profiling: an event pair around each kernel launch ----
+void prof_reset(pp_engine* e) { e->ktimes.clear(); e->ev_used = 0; }
+
+int prof_event(pp_engine* e) {
+    if (e->ev_used == (int)e->events.size()) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return -1;
+        e->events.push_back(ev);
+    }
+    return e->ev_used++;
+}
+
+struct ProfScope {
+    pp_engine* e;
+    int e1 = -1;
+    ProfScope(pp_engine* en, const char* name) : e(en) {
+        if (e->prof <= 0) return;
+        int e0 = prof_event(e);
+        e1 = prof_event(e);
+        if (e0 < 0 || e1 < 0) { e1 = -1; return; }
+        (void)hipEventRecord(e->events[e0], e->stream);
+        e->ktimes.push_back({name, e0});
+    }
+    ~ProfScope() {
+        if (e1 >= 0) (void)hipEventRecord(e->events[e1], e->stream);
+    }
+};
+
+int bits_ok(const pp_config& c) {
+    for (int j = 0; j < 3; ++j)
+        if (!(c.voxel_size[j] > 0.0) || !(c.pc_range[3 + j] > c.pc_range[j])) return 0;
+    return 1;
+}
+
+const char* kBn[4] = {"gamma", "beta", "moving_mean", "moving_variance"};
+
+const std::vector<float>* getw(pp_engine* e, const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = e->hw.find(name);
+    if (it == e->hw.end()) { e->err = "missing weight tensor '" + name + "'"; return nullptr; }
+    const auto& sh = e->hshape[name];
+    std::vector<int64_t> want(shape);
+    if (sh != want) {
+        std::string s = "weight '" + name + "' has shape [";
+        for (auto v : sh) s += std::to_string(v) + ",";
+        s += "] expected [";
+        for (auto v : want) s += std::to_string(v) + ",";
+        s += "]";
+        e->err = s;
+        return nullptr;
+    }
+    return &it->second;
+}
+
+// BatchNorm inference folded to y = x*scale + shift (eps 1e-3: model/pointpillars.py:109; Keras default for the RPN)
+bool bn_fold(pp_engine* e, const std::string& prefix, int c, std::vector<float>& scale, std::vector<float>& shift) {
+    const std::vector<float>* p[4];
+    for (int i = 0; i < 4; ++i) {
+        p[i] = getw(e, prefix + "/" + kBn[i], {c});
+        if (!p[i]) return false;
+    }
+    scale.resize(c);
+    shift.resize(c);
+    for (int i = 0; i < c; ++i) {
+        const float inv = (*p[0])[i] / sqrtf((*p[3])[i] + 1e-3f);
+        scale[i] = inv;
+        shift[i] = (*p[1])[i] - (*p[2])[i] * inv;
+    }
+    return true;
+}
+
+int upload(pp_engine* e, float** d, const std::vector<float>& h) {
+    int st = dalloc(e, d, h.size());
+    if (st) return st;
+    HIPCHK(e, hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PP_OK;
+}
+
+// ---- stage pipelines (all enqueue on e->stream) ----
+int run_voxelize(pp_engine* e, int batch, int max_n) {
+    {
+        ProfScope ps(e, "memset_first");
+        HIPCHK(e, hipMemsetAsync(e->d_first, 0x7f, (size_t)batch * e->ncell * sizeof(int), e->stream));
+    }
+    {
+        ProfScope ps(e, "memset_cellmap");
+        HIPCHK(e, hipMemsetAsync(e->d_cellmap, 0xff, (size_t)batch * e->ncell * sizeof(int), e->stream));
+    }
+    {
+        ProfScope ps(e, "k_cell_first");
+        launch_cell_first(e->d_points, e->d_offsets, batch, max_n, e->F, e->geom, e->d_cell, e->d_first, e->stream);
+    }
+    {
+        ProfScope ps(e, "k_voxel_frame");
+        launch_voxel_frame(e->d_offsets, e->d_cell, e->d_first, e->d_cellmap, e->d_keyA, e->d_idxA, e->d_keyB,
+                           e->d_idxB, e->d_pstart, e->d_pcell, e->d_npillars, e->d_nvalid, batch, e->ncell,
+                           e->cfg.max_voxels, e->stream);
+    }
+    HIPCHK(e, hipGetLastError());
+    return PP_OK;
+}
+
+const unsigned* sorted_idx(pp_engine* e) {
+    return (voxel_sort_passes(e->cfg.max_voxels) % 2 == 0) ? e->d_idxA : e->d_idxB;
+}
+
+int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out) {
+    PfnParams p;
+    memset(&p, 0, sizeof(p));
+    p.batch = batch; p.nz = e->nz; p.ny = e->ny; p.nx = e->nx; p.C = e->C; p.F = e->F; p.T = e->T;
+    p.max_voxels = e->cfg.max_voxels;
+    p.vx = (float)e->cfg.voxel_size[0];
+    p.vy = (float)e->cfg.voxel_size[1];
+    // Python-float64 arithmetic, then a float32 constant (model/pointpillars.py:121-124)
+    p.x_off = (float)(e->cfg.voxel_size[0] / 2 + e->cfg.pc_range[0]);
+    p.y_off = (float)(e->cfg.voxel_size[1] / 2 + e->cfg.pc_range[1]);
+    p.w = e->d_pfn_w; p.bias = e->d_pfn_b; p.cellmap = e->d_cellmap;
+    p.pts = e->d_points; p.offsets = e->d_offsets; p.sorted_idx = sorted_idx(e); p.pillar_start = e->d_pstart;
+    p.voxels = e->d_voxels; p.num_points = e->d_numpts;
+    p.canvas = e->d_canvas; p.feat_out = feat_out;
+    ProfScope ps(e, "k_pfn_canvas");
+    int st = launch_pfn(p, padded, e->stream);
+    if (st) return fail(e, st, "PFN: unsupported C=%d / F=%d", e->C, e->F);
+    HIPCHK(e, hipGetLastError());
+    return PP_OK;
+}
+
+int run_anchor_mask(pp_engine* e, int batch) {
+    ProfScope ps(e, "anchor_mask(3 kernels)");
+    launch_anchor_mask(e->d_cellmap, batch, e->nz, e->ny, e->nx, e->d_cells, e->A, e->cfg.anchor_area_threshold,
+                       e->d_integ, e->d_mask, e->stream);
+    HIPCHK(e, hipGetLastError());
+    return PP_OK;
+}
+
+int run_backbone(pp_engine* e, int batch) {
+    for (const LayerDesc& L : e->layers) {
+        ProfScope ps(e, L.name);
+        int st = launch_layer(L, batch, e->d_box, e->d_cls, e->d_dir, e->napl, e->stream);
+        if (st) return fail(e, st, "layer %s: unsupported shape (cin=%d cout=%d)", L.name, L.cin, L.cout);
+    }
+    HIPCHK(e, hipGetLastError());
+    return PP_OK;
+}
+
+int run_post(pp_engine* e, int batch) {
+    PostParams p;
+    p.batch = batch; p.A = e->A; p.pre_max = e->cfg.nms_pre_max_size; p.post_max = e->cfg.nms_post_max_size;
+    p.score_thr = e->cfg.nms_score_threshold; p.iou_thr = e->cfg.nms_iou_threshold;
+    p.box = e->d_box; p.cls = e->d_cls; p.dir = e->d_dir; p.mask = e->d_mask; p.anchors = e->d_anchors;
+    p.calib = e->d_calib; p.dets = e->d_dets; p.n_dets = e->d_ndets;
+    ProfScope ps(e, "k_postprocess");
+    launch_postprocess(p, e->stream);
+    HIPCHK(e, hipGetLastError());
+    return PP_OK;
+}
+
+int check_batch(pp_engine* e, int batch) {
+    if (batch < 1 || batch > e->B) return fail(e, PP_ERR_ARG, "batch %d outside [1, max_batch=%d]", batch, e->B);
+    return PP_OK;
+}
+
+int set_offsets(pp_engine* e, const int32_t* off, int batch) {
+    if (!off) return fail(e, PP_ERR_ARG, "frame_offsets is NULL");
+    if (off[0] != 0) return fail(e, PP_ERR_ARG, "frame_offsets[0] must be 0");
+    int max_n = 0;
+    for (int b = 0; b < batch; ++b) {
+        const int n = off[b + 1] - off[b];
+        if (n < 0) return fail(e, PP_ERR_ARG, "frame_offsets not monotone at frame %d", b);
+        if (n > e->NMAX) return fail(e, PP_ERR_ARG, "frame %d has %d points > max_points_per_frame=%d", b, n, e->NMAX);
+        if (n > max_n) max_n = n;
+    }
+    e->h_offsets.assign(off, off + batch + 1);
+    e->cur_batch = batch;
+    e->cur_max_n = max_n;
+    HIPCHK(e, hipMemcpyAsync(e->d_offsets, e->h_offsets.data(), (batch + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    return PP_OK;
+}
+
+void calib_matrix(const float* rect, const float* trv, float* M) {
+    // r_rect @ velo2cam in float32 (libraries/eval_helper_functions.py:732)
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < 4; ++k) s += rect[i * 4 + k] * trv[k * 4 + j];
+            M[i * 4 + j] = s;
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pp_abi_version(void) { return PP_ABI_VERSION; }
+
+const char* pp_last_error(pp_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pp_create(const pp_config* cfg, int device, pp_handle* out) {
+    if (!cfg || !out) return fail(nullptr, PP_ERR_ARG, "pp_create: NULL argument");
+    *out = nullptr;
+    if (!bits_ok(*cfg)) return fail(nullptr, PP_ERR_ARG, "pp_create: bad range / voxel size");
+    if (cfg->max_points < 1 || cfg->max_voxels < 1 || cfg->max_batch < 1 || cfg->max_points_per_frame < 1)
+        return fail(nullptr, PP_ERR_ARG, "pp_create: max_points / max_voxels / max_batch / max_points_per_frame must be >= 1");
+    if (cfg->num_point_features != 3 && cfg->num_point_features != 4)
+        return fail(nullptr, PP_ERR_UNSUPPORTED, "pp_create: num_point_features must be 3 or 4");
+    if (cfg->num_class != 1) return fail(nullptr, PP_ERR_UNSUPPORTED, "pp_create: only num_class == 1 is implemented (as in the reference's predict())");
+    if (cfg->num_anchor_per_loc < 1 || cfg->num_anchor_per_loc * 10 > 32)
+        return fail(nullptr, PP_ERR_UNSUPPORTED, "pp_create: num_anchor_per_loc must be 1..3");
+    if (cfg->nms_post_max_size < 1 || cfg->nms_pre_max_size < 1)
+        return fail(nullptr, PP_ERR_ARG, "pp_create: nms sizes must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, PP_ERR_HIP, "pp_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, PP_ERR_ARG, "pp_create: device %d not in [0,%d)", device, ndev);
+    pp_engine* e = new pp_engine();
+    e->cfg = *cfg;
+    e->device = device;
+    hipError_t st = hipSetDevice(device);
+    if (st == hipSuccess) st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (st != hipSuccess) {
+        fail(nullptr, PP_ERR_HIP, "pp_create: %s", hipGetErrorString(st));
+        delete e;
+        return PP_ERR_HIP;
+    }
+    for (int j = 0; j < 3; ++j) {
+        e->geom.lo[j] = cfg->pc_range[j];
+        e->geom.vs[j] = cfg->voxel_size[j];
+        e->geom.grid[j] = (int)nearbyint((cfg->pc_range[3 + j] - cfg->pc_range[j]) / cfg->voxel_size[j]);
+    }
+    e->nx = e->geom.grid[0]; e->ny = e->geom.grid[1]; e->nz = e->geom.grid[2];
+    e->ncell = e->nx * e->ny * e->nz;
+    e->geom.ncell = e->ncell;
+    e->C = cfg->pfn_filters; e->F = cfg->num_point_features; e->T = cfg->max_points; e->FA = e->F + 5;
+    e->B = cfg->max_batch; e->NMAX = cfg->max_points_per_frame;
+    e->napl = cfg->num_anchor_per_loc;
+    const int osf = cfg->layer_strides[0] / cfg->upsample_strides[0];
+    if (osf < 1 || e->nx < 1 || e->ny < 1 || e->nz < 1) {
+        fail(nullptr, PP_ERR_ARG, "pp_create: degenerate grid");
+        delete e;
+        return PP_ERR_ARG;
+    }
+    e->head_h = e->ny / osf; e->head_w = e->nx / osf;
+    e->A = (int64_t)e->head_h * e->head_w * e->napl;
+    e->CC = cfg->num_upsample_filters[0] + cfg->num_upsample_filters[1] + cfg->num_upsample_filters[2];
+
+    // layer table + map sizes
+    int st2 = PP_OK;
+    {
+        int h = e->ny, w = e->nx, cin = e->C;
+        size_t act_max = 1;
+        int co_off = 0;
+        static const char* sep_names[3][8] = {
+            {"block1.0", "block1.1", "block1.2", "block1.3", "block1.4", "block1.5", "block1.6", "block1.7"},
+            {"block2.0", "block2.1", "block2.2", "block2.3", "block2.4", "block2.5", "block2.6", "block2.7"},
+            {"block3.0", "block3.1", "block3.2", "block3.3", "block3.4", "block3.5", "block3.6", "block3.7"}};
+        static const char* dec_names[3] = {"deconv1", "deconv2", "deconv3"};
+        for (int b = 0; b < 3 && st2 == PP_OK; ++b) {
+            if (cfg->layer_nums[b] < 0 || cfg->layer_nums[b] > 7) { st2 = fail(nullptr, PP_ERR_UNSUPPORTED, "layer_nums[%d] must be 0..7", b); break; }
+            for (int j = 0; j <= cfg->layer_nums[b]; ++j) {
+                LayerDesc L;
+                memset(&L, 0, sizeof(L));
+                L.kind = LAYER_SEP; L.cin = cin; L.cout = cfg->num_filters[b];
+                L.stride = (j == 0) ? cfg->layer_strides[b] : 1;
+                L.in_h = h; L.in_w = w;
+                L.out_h = (h + 2 - 3) / L.stride + 1; L.out_w = (w + 2 - 3) / L.stride + 1;
+                L.n_total = L.cout; L.ld_out = L.cout; L.co_off = 0; L.name = sep_names[b][j];
+                e->layers.push_back(L);
+                h = L.out_h; w = L.out_w; cin = L.cout;
+                act_max = std::max(act_max, (size_t)e->B * h * w * cin);
+            }
+            LayerDesc D;
+            memset(&D, 0, sizeof(D));
+            D.kind = LAYER_DECONV; D.cin = cin; D.cout = cfg->num_upsample_filters[b]; D.k = cfg->upsample_strides[b];
+            D.in_h = h; D.in_w = w; D.out_h = h * D.k; D.out_w = w * D.k;
+            D.n_total = D.k * D.k * D.cout; D.ld_out = e->CC; D.co_off = co_off; D.name = dec_names[b];
+            if (D.out_h != e->head_h || D.out_w != e->head_w)
+                st2 = fail(nullptr, PP_ERR_SHAPE, "deconv%d output %dx%d != head map %dx%d", b + 1, D.out_h, D.out_w, e->head_h, e->head_w);
+            co_off += D.cout;
+            e->layers.push_back(D);
+        }
+        if (st2 == PP_OK) {
+            LayerDesc H;
+            memset(&H, 0, sizeof(H));
+            H.kind = LAYER_HEAD; H.cin = e->CC; H.cout = 32; H.in_h = e->head_h; H.in_w = e->head_w;
+            H.out_h = e->head_h; H.out_w = e->head_w; H.n_total = 32; H.name = "heads";
+            e->layers.push_back(H);
+        }
+        if (st2 == PP_OK) {
+            pp_engine* q = e;
+            const size_t BN = (size_t)e->B * e->NMAX;
+            const size_t BMV = (size_t)e->B * cfg->max_voxels;
+            const size_t HW = (size_t)e->head_h * e->head_w;
+            auto A1 = [&](int s) { if (st2 == PP_OK) st2 = s; };
+            A1(dalloc(q, &e->d_points, BN * e->F));
+            A1(dalloc(q, &e->d_offsets, (size_t)e->B + 1));
+            A1(dalloc(q, &e->d_cell, BN));
+            A1(dalloc(q, &e->d_first, (size_t)e->B * e->ncell));
+            A1(dalloc(q, &e->d_cellmap, (size_t)e->B * e->ncell));
+            A1(dalloc(q, &e->d_keyA, BN)); A1(dalloc(q, &e->d_idxA, BN));
+            A1(dalloc(q, &e->d_keyB, BN)); A1(dalloc(q, &e->d_idxB, BN));
+            A1(dalloc(q, &e->d_pstart, (size_t)e->B * (cfg->max_voxels + 1)));
+            A1(dalloc(q, &e->d_pcell, BMV));
+            A1(dalloc(q, &e->d_npillars, (size_t)e->B));
+            A1(dalloc(q, &e->d_nvalid, (size_t)e->B));
+            A1(dalloc(q, &e->d_canvas, (size_t)e->B * e->ny * e->nx * e->C));
+            A1(dalloc(q, &e->d_act[0], act_max));
+            A1(dalloc(q, &e->d_act[1], act_max));
+            A1(dalloc(q, &e->d_concat, (size_t)e->B * HW * e->CC));
+            A1(dalloc(q, &e->d_box, (size_t)e->B * HW * e->napl * 7));
+            A1(dalloc(q, &e->d_cls, (size_t)e->B * HW * e->napl));
+            A1(dalloc(q, &e->d_dir, (size_t)e->B * HW * e->napl * 2));
+            A1(dalloc(q, &e->d_integ, (size_t)e->B * e->ny * e->nx));
+            A1(dalloc(q, &e->d_mask, (size_t)e->B * e->A));
+            A1(dalloc(q, &e->d_anchors, (size_t)e->A * 7));
+            A1(dalloc(q, &e->d_cells, (size_t)e->A * 4));
+            A1(dalloc(q, &e->d_calib, (size_t)e->B * 16));
+            A1(dalloc(q, &e->d_dets, (size_t)e->B * cfg->nms_post_max_size));
+            A1(dalloc(q, &e->d_ndets, (size_t)e->B));
+            if (st2 == PP_OK && hipHostMalloc((void**)&e->h_dets, (size_t)e->B * cfg->nms_post_max_size * sizeof(pp_detection)) != hipSuccess) st2 = PP_ERR_HIP;
+            if (st2 == PP_OK && hipHostMalloc((void**)&e->h_ndets, (size_t)e->B * sizeof(int)) != hipSuccess) st2 = PP_ERR_HIP;
+            if (st2 == PP_OK && (hipEventCreate(&e->t0) != hipSuccess || hipEventCreate(&e->t1) != hipSuccess)) st2 = PP_ERR_HIP;
+            if (st2 == PP_OK) {
+                // identity calibration until pp_set_calib
+                std::vector<float> I((size_t)e->B * 16, 0.f);
+                for (int b = 0; b < e->B; ++b) for (int d = 0; d < 4; ++d) I[(size_t)b * 16 + d * 5] = 1.f;
+                if (hipMemcpy(e->d_calib, I.data(), I.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) st2 = PP_ERR_HIP;
+            }
+            if (st2 != PP_OK && g_create_error.empty()) g_create_error = e->err.empty() ? "pp_create: allocation failed" : e->err;
+            if (st2 != PP_OK && !e->err.empty()) g_create_error = e->err;
+        }
+        // wire activation buffers: ping-pong inside the blocks, deconvs into the concat buffer
+        if (st2 == PP_OK) {
+            const float* cur = e->d_canvas;
+            int pp = 0;
+            for (LayerDesc& L : e->layers) {
+                if (L.kind == LAYER_SEP) { L.in = cur; L.out = e->d_act[pp]; cur = L.out; pp ^= 1; }
+                else if (L.kind == LAYER_DECONV) { L.in = cur; L.out = e->d_concat; }
+                else { L.in = e->d_concat; L.out = nullptr; }
+            }
+        }
+    }
+    if (st2 != PP_OK) { pp_destroy(e); return st2; }
+    *out = e;
+    return PP_OK;
+}
+
+int pp_destroy(pp_handle e) {
+    if (!e) return PP_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->d_voxels) (void)hipFree(e->d_voxels);
+    if (e->d_numpts) (void)hipFree(e->d_numpts);
+    if (e->d_coors) (void)hipFree(e->d_coors);
+    if (e->d_feat) (void)hipFree(e->d_feat);
+    if (e->h_dets) (void)hipHostFree(e->h_dets);
+    if (e->h_ndets) (void)hipHostFree(e->h_ndets);
+    for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    if (e->t0) (void)hipEventDestroy(e->t0);
+    if (e->t1) (void)hipEventDestroy(e->t1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return PP_OK;
+}
+
+int pp_set_weight(pp_handle e, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!e) return PP_ERR_ARG;
+    if (!name || !data || !shape || ndim < 1 || ndim > 4) return fail(e, PP_ERR_ARG, "pp_set_weight: bad argument");
+    size_t n = 1;
+    std::vector<int64_t> sh(shape, shape + ndim);
+    for (auto v : sh) { if (v < 1) return fail(e, PP_ERR_SHAPE, "pp_set_weight(%s): non-positive dim", name); n *= (size_t)v; }
+    e->hw[name].assign(data, data + n);
+    e->hshape[name] = sh;
+    e->weights_ready = false;
+    return PP_OK;
+}
+
+int pp_finalize_weights(pp_handle e) {
+    if (!e) return PP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    std::vector<float> sc, sh;
+    // PFN: dense [Fa,C] * scale, bias = shift
+    {
+        const auto* k = getw(e, "pfn/dense/kernel", {e->FA, e->C});
+        if (!k || !bn_fold(e, "pfn/bn", e->C, sc, sh)) return PP_ERR_SHAPE;
+        std::vector<float> w((size_t)e->FA * e->C);
+        for (int f = 0; f < e->FA; ++f)
+            for (int c = 0; c < e->C; ++c) w[(size_t)f * e->C + c] = (*k)[(size_t)f * e->C + c] * sc[c];
+        int st = upload(e, &e->d_pfn_w, w); if (st) return st;
+        st = upload(e, &e->d_pfn_b, sh); if (st) return st;
+    }
+    int bi = 0, li = 0;
+    for (LayerDesc& L : e->layers) {
+        if (L.kind == LAYER_SEP) {
+            const std::string pre = "rpn/block" + std::to_string(bi + 1) + "/" + std::to_string(li);
+            const auto* dw = getw(e, pre + "/depthwise_kernel", {3, 3, L.cin, 1});
+            const auto* pw = getw(e, pre + "/pointwise_kernel", {1, 1, L.cin, L.cout});
+            if (!dw || !pw || !bn_fold(e, pre + "/bn", L.cout, sc, sh)) return PP_ERR_SHAPE;
+            std::vector<float> wt((size_t)L.cout * L.cin);
+            for (int ci = 0; ci < L.cin; ++ci)
+                for (int co = 0; co < L.cout; ++co) wt[(size_t)co * L.cin + ci] = (*pw)[(size_t)ci * L.cout + co] * sc[co];
+            int st = upload(e, &L.d_dw, *dw); if (st) return st;
+            st = upload(e, &L.d_wt, wt); if (st) return st;
+            st = upload(e, &L.d_bias, sh); if (st) return st;
+            ++li;
+        } else if (L.kind == LAYER_DECONV) {
+            const std::string pre = "rpn/deconv" + std::to_string(bi + 1);
+            const auto* k = getw(e, pre + "/kernel", {L.k, L.k, L.cout, L.cin});
+            if (!k || !bn_fold(e, pre + "/bn", L.cout, sc, sh)) return PP_ERR_SHAPE;
+            std::vector<float> wt(k->size());
+            for (size_t n = 0; n < (size_t)L.n_total; ++n) {
+                const int co = (int)(n % L.cout);
+                for (int ci = 0; ci < L.cin; ++ci) wt[n * L.cin + ci] = (*k)[n * L.cin + ci] * sc[co];
+            }
+            int st = upload(e, &L.d_wt, wt); if (st) return st;
+            st = upload(e, &L.d_bias, sh); if (st) return st;
+            ++bi; li = 0;
+        } else {
+            const int nb = e->napl * 7, nc = e->napl, nd = e->napl * 2;
+            const auto* kb = getw(e, "rpn/conv_box/kernel", {1, 1, L.cin, nb});
+            const auto* bb = getw(e, "rpn/conv_box/bias", {nb});
+            const auto* kc = getw(e, "rpn/conv_cls/kernel", {1, 1, L.cin, nc});
+            const auto* bc = getw(e, "rpn/conv_cls/bias", {nc});
+            const auto* kd = getw(e, "rpn/conv_dir_cls/kernel", {1, 1, L.cin, nd});
+            const auto* bd = getw(e, "rpn/conv_dir_cls/bias", {nd});
+            if (!kb || !bb || !kc || !bc || !kd || !bd) return PP_ERR_SHAPE;
+            std::vector<float> wt((size_t)32 * L.cin, 0.f), bias(32, 0.f);
+            for (int ci = 0; ci < L.cin; ++ci) {
+                for (int o = 0; o < nb; ++o) wt[(size_t)o * L.cin + ci] = (*kb)[(size_t)ci * nb + o];
+                for (int o = 0; o < nc; ++o) wt[(size_t)(nb + o) * L.cin + ci] = (*kc)[(size_t)ci * nc + o];
+                for (int o = 0; o < nd; ++o) wt[(size_t)(nb + nc + o) * L.cin + ci] = (*kd)[(size_t)ci * nd + o];
+            }
+            for (int o = 0; o < nb; ++o) bias[o] = (*bb)[o];
+            for (int o = 0; o < nc; ++o) bias[nb + o] = (*bc)[o];
+            for (int o = 0; o < nd; ++o) bias[nb + nc + o] = (*bd)[o];
+            int st = upload(e, &L.d_wt, wt); if (st) return st;
+            st = upload(e, &L.d_bias, bias); if (st) return st;
+        }
+    }
+    e->weights_ready = true;
+    return PP_OK;
+}
+
+int pp_set_anchors(pp_handle e, const float* anchors, const int32_t* cells, int64_t num_anchors) {
+    if (!e) return PP_ERR_ARG;
+    if (!anchors || !cells) return fail(e, PP_ERR_ARG, "pp_set_anchors: NULL argument");
+    if (num_anchors != e->A) return fail(e, PP_ERR_SHAPE, "pp_set_anchors: got %lld anchors, config needs %lld", (long long)num_anchors, (long long)e->A);
+    for (int64_t a = 0; a < num_anchors; ++a) {
+        const int32_t* c = cells + a * 4;
+        if (c[0] < 0 || c[1] < 0 || c[2] >= e->nx || c[3] >= e->ny || c[0] >= e->nx || c[1] >= e->ny || c[2] < 0 || c[3] < 0)
+            return fail(e, PP_ERR_ARG, "pp_set_anchors: anchor %lld cells out of the %dx%d grid", (long long)a, e->nx, e->ny);
+    }
+    (void)hipSetDevice(e->device);
+    HIPCHK(e, hipMemcpy(e->d_anchors, anchors, (size_t)num_anchors * 7 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->d_cells, cells, (size_t)num_anchors * 4 * sizeof(int), hipMemcpyHostToDevice));
+    e->anchors_ready = true;
+    return PP_OK;
+}
+
+int pp_upload_points(pp_handle e, const float* points, const int32_t* frame_offsets, int32_t batch) {
+    if (!e) return PP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    int st = check_batch(e, batch); if (st) return st;
+    st = set_offsets(e, frame_offsets, batch); if (st) return st;
+    const size_t n = (size_t)frame_offsets[batch];
+    if (n && !points) return fail(e, PP_ERR_ARG, "pp_upload_points: points is NULL");
+    if (n) HIPCHK(e, hipMemcpyAsync(e->d_points, points, n * e->F * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));  // the host buffers may be pageable / reused by the caller
+    return PP_OK;
+}
+
+int pp_upload_points_device(pp_handle e, const void* points_dev, const int32_t* frame_offsets, int32_t batch) {
+    if (!e) return PP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    int st = check_batch(e, batch); if (st) return st;
+    st = set_offsets(e, frame_offsets, batch); if (st) return st;
+    const size_t n = (size_t)frame_offsets[batch];
+    if (n && !points_dev) return fail(e, PP_ERR_ARG, "pp_upload_points_device: points is NULL");
+    if (n) HIPCHK(e, hipMemcpyAsync(e->d_points, points_dev, n * e->F * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    return PP_OK;
+}
+
+int pp_set_calib(pp_handle e, const float* rect, const float* trv2c, int32_t batch) {
+    if (!e) return PP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    int st = check_batch(e, batch); if (st) return st;
+    if (!rect || !trv2c) return fail(e, PP_ERR_ARG, "pp_set_calib: NULL argument");
+    std::vector<float> M((size_t)batch * 16);
+    for (int b = 0; b < batch; ++b) calib_matrix(rect + (size_t)b * 16, trv2c + (size_t)b * 16, M.data() + (size_t)b * 16);
+    HIPCHK(e, hipMemcpy(e->d_calib, M.data(), M.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PP_OK;
+}
+
+int pp_detect_async(pp_handle e) {
+    if (!e) return PP_ERR_ARG;
+    if (!e->weights_ready) return fail(e, PP_ERR_STATE, "pp_detect_async: weights not finalised");
+    if (!e->anchors_ready) return fail(e, PP_ERR_STATE, "pp_detect_async: anchors not set");
+    if (e->cur_batch < 1) return fail(e, PP_ERR_STATE, "pp_detect_async: no frames uploaded");
+    (void)hipSetDevice(e->device);
+    const int B = e->cur_batch;
+    prof_reset(e);
+    int st;
+    if ((st = run_voxelize(e, B, e->cur_max_n))) return st;
+    if ((st = run_pfn(e, B, false, nullptr))) return st;
+    if ((st = run_anchor_mask(e, B))) return st;
+    if ((st = run_backbone(e, B))) return st;
+    if ((st = run_post(e, B))) return st;
+    HIPCHK(e, hipMemcpyAsync(e->h_dets, e->d_dets, (size_t)B * e->cfg.nms_post_max_size * sizeof(pp_detection), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->h_ndets, e->d_ndets, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    return PP_OK;
+}
+
+int pp_sync(pp_handle e) {
+    if (!e) return PP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return PP_OK;
+}
+
+int pp_get_detections(pp_handle e, pp_detection* dets, int32_t* n_dets) {
+    if (!e) return PP_ERR_ARG;
+    if (!dets || !n_dets) return fail(e, PP_ERR_ARG, "pp_get_detections: NULL argument");
+    const int B = e->cur_batch;
+    memcpy(dets, e->h_dets, (size_t)B * e->cfg.nms_post_max_size * sizeof(pp_detection));
+    memcpy(n_dets, e->h_ndets, (size_t)B * sizeof(int));
+    return PP_OK;
+}
+
+int pp_detect(pp_handle e, const float* points, const int32_t* frame_offsets, int32_t batch, const float* rect,
+              const float* trv2c, pp_detection* dets, int32_t* n_dets) {
+    int st;
+    if ((st = pp_upload_points(e, points, frame_offsets, batch))) return st;
+    if (rect && trv2c && (st = pp_set_calib(e, rect, trv2c, batch))) return st;
+    if ((st = pp_detect_async(e))) return st;
+    if ((st = pp_sync(e))) return st;
+    return pp_get_detections(e, dets, n_dets);
+}
+
+int pp_points_to_voxel(pp_handle e, const float* points, int64_t n, float* voxels, int32_t* coors,
+                       int32_t* num_points, int32_t* n_pillars) {
+    if (!e) return PP_ERR_ARG;
+    if (!voxels || !coors || !num_points || !n_pillars) return fail(e, PP_ERR_ARG, "pp_points_to_voxel: NULL output");
+    if (n < 0 || n > e->NMAX) return fail(e, PP_ERR_ARG, "pp_points_to_voxel: n=%lld outside [0, max_points_per_frame=%d]", (long long)n, e->NMAX);
+    (void)hipSetDevice(e->device);
+    const int32_t off[2] = {0, (int32_t)n};
+    int st = pp_upload_points(e, points, off, 1); if (st) return st;
+    prof_reset(e);
+    if ((st = run_voxelize(e, 1, (int)n))) return st;
+    const size_t MV = (size_t)e->cfg.max_voxels;
+    if ((st = dgrow(e, &e->d_voxels, &e->cap_voxels, MV * e->T * e->F))) return st;
+    if ((st = dgrow(e, &e->d_numpts, &e->cap_numpts, MV))) return st;
+    if ((st = dgrow(e, &e->d_coors, &e->cap_coors, MV * 4))) return st;
+    launch_voxel_expand(e->d_points, e->d_offsets, sorted_idx(e), e->d_pstart, e->d_pcell, e->d_npillars, 0, e->F,
+                        e->T, e->cfg.max_voxels, e->ny, e->nx, e->d_voxels, e->d_coors, e->d_numpts, e->stream);
+    HIPCHK(e, hipGetLastError());
+    int P = 0;
+    HIPCHK(e, hipMemcpyAsync(&P, e->d_npillars, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (P < 0 || P > e->cfg.max_voxels) return fail(e, PP_ERR_HIP, "pp_points_to_voxel: device returned %d pillars", P);
+    *n_pillars = P;
+    if (P) {
+        HIPCHK(e, hipMemcpy(voxels, e->d_voxels, (size_t)P * e->T * e->F * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(coors, e->d_coors, (size_t)P * 3 * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(num_points, e->d_numpts, (size_t)P * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return PP_OK;
+}
+
+static int upload_coors(pp_engine* e, const int32_t* coors, int64_t P, int32_t batch, const char* who) {
+    for (int64_t p = 0; p < P; ++p) {
+        const int32_t* c = coors + p * 4;
+        if (c[0] < 0 || c[0] >= batch || c[1] < 0 || c[1] >= e->nz || c[2] < 0 || c[2] >= e->ny || c[3] < 0 || c[3] >= e->nx)
+            return fail(e, PP_ERR_ARG, "%s: coors[%lld] = (%d,%d,%d,%d) outside batch=%d / grid z%d y%d x%d", who,
+                        (long long)p, c[0], c[1], c[2], c[3], batch, e->nz, e->ny, e->nx);
+    }
+    int st = dgrow(e, &e->d_coors, &e->cap_coors, (size_t)P * 4); if (st) return st;
+    if (P) HIPCHK(e, hipMemcpyAsync(e->d_coors, coors, (size_t)P * 4 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_cellmap, 0xff, (size_t)batch * e->ncell * sizeof(int), e->stream));
+    launch_build_cellmap(e->d_coors, P, e->ncell, e->ny, e->nx, e->d_cellmap, e->stream);
+    HIPCHK(e, hipGetLastError());
+    return PP_OK;
+}
+
+int pp_anchor_mask(pp_handle e, const int32_t* coors, int64_t num_pillars, int32_t batch, uint8_t* mask) {
+    if (!e) return PP_ERR_ARG;
+    if (!e->anchors_ready) return fail(e, PP_ERR_STATE, "pp_anchor_mask: anchors not set");
+    if ((num_pillars && !coors) || !mask || num_pillars < 0) return fail(e, PP_ERR_ARG, "pp_anchor_mask: bad argument");
+    (void)hipSetDevice(e->device);
+    int st = check_batch(e, batch); if (st) return st;
+    if ((st = upload_coors(e, coors, num_pillars, batch, "pp_anchor_mask"))) return st;
+    prof_reset(e);
+    if ((st = run_anchor_mask(e, batch))) return st;
+    HIPCHK(e, hipMemcpyAsync(mask, e->d_mask, (size_t)batch * e->A, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return PP_OK;
+}
+
+int pp_forward_voxels(pp_handle e, const float* voxels, const int32_t* num_points, const int32_t* coors,
+                      int64_t P, int32_t batch, float* box_preds, float* cls_preds, float* dir_cls_preds,
+                      float* pillar_features, float* canvas) {
+    if (!e) return PP_ERR_ARG;
+    if (!e->weights_ready) return fail(e, PP_ERR_STATE, "pp_forward_voxels: weights not finalised");
+    if (P < 0 || (P && (!voxels || !num_points || !coors)) || !box_preds || !cls_preds || !dir_cls_preds)
+        return fail(e, PP_ERR_ARG, "pp_forward_voxels: NULL argument");
+    (void)hipSetDevice(e->device);
+    int st = check_batch(e, batch); if (st) return st;
+    for (int64_t p = 0; p < P; ++p)
+        if (num_points[p] < 1 || num_points[p] > e->T)
+            return fail(e, PP_ERR_ARG, "pp_forward_voxels: num_points[%lld]=%d outside [1,%d]", (long long)p, num_points[p], e->T);
+    if ((st = upload_coors(e, coors, P, batch, "pp_forward_voxels"))) return st;
+    if ((st = dgrow(e, &e->d_voxels, &e->cap_voxels, (size_t)P * e->T * e->F))) return st;
+    if ((st = dgrow(e, &e->d_numpts, &e->cap_numpts, (size_t)P))) return st;
+    if (pillar_features && (st = dgrow(e, &e->d_feat, &e->cap_feat, (size_t)P * e->C))) return st;
+    if (P) {
+        HIPCHK(e, hipMemcpyAsync(e->d_voxels, voxels, (size_t)P * e->T * e->F * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->d_numpts, num_points, (size_t)P * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    }
+    prof_reset(e);
+    if ((st = run_pfn(e, batch, true, pillar_features ? e->d_feat : nullptr))) return st;
+    if ((st = run_backbone(e, batch))) return st;
+    const size_t HW = (size_t)e->head_h * e->head_w;
+    HIPCHK(e, hipMemcpyAsync(box_preds, e->d_box, (size_t)batch * HW * e->napl * 7 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(cls_preds, e->d_cls, (size_t)batch * HW * e->napl * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(dir_cls_preds, e->d_dir, (size_t)batch * HW * e->napl * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (pillar_features && P)
+        HIPCHK(e, hipMemcpyAsync(pillar_features, e->d_feat, (size_t)P * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (canvas)
+        HIPCHK(e, hipMemcpyAsync(canvas, e->d_canvas, (size_t)batch * e->ny * e->nx * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return PP_OK;
+}
+
+int pp_predict(pp_handle e, const float* box_preds, const float* cls_preds, const float* dir_cls_preds,
+               const uint8_t* anchors_mask, const float* rect, const float* trv2c, int32_t batch,
+               pp_detection* dets, int32_t* n_dets) {
+    if (!e) return PP_ERR_ARG;
+    if (!e->anchors_ready) return fail(e, PP_ERR_STATE, "pp_predict: anchors not set");
+    if (!box_preds || !cls_preds || !dir_cls_preds || !anchors_mask || !rect || !trv2c || !dets || !n_dets)
+        return fail(e, PP_ERR_ARG, "pp_predict: NULL argument");
+    (void)hipSetDevice(e->device);
+    int st = check_batch(e, batch); if (st) return st;
+    if ((st = pp_set_calib(e, rect, trv2c, batch))) return st;
+    const size_t HW = (size_t)e->head_h * e->head_w;
+    HIPCHK(e, hipMemcpyAsync(e->d_box, box_preds, (size_t)batch * HW * e->napl * 7 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_cls, cls_preds, (size_t)batch * HW * e->napl * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_dir, dir_cls_preds, (size_t)batch * HW * e->napl * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_mask, anchors_mask, (size_t)batch * e->A, hipMemcpyHostToDevice, e->stream));
+    prof_reset(e);
+    if ((st = run_post(e, batch))) return st;
+    HIPCHK(e, hipMemcpyAsync(dets, e->d_dets, (size_t)batch * e->cfg.nms_post_max_size * sizeof(pp_detection), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(n_dets, e->d_ndets, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return PP_OK;
+}
+
+int pp_fetch_intermediates(pp_handle e, int32_t* n_pillars, int32_t* coors, int32_t* num_points,
+                           uint8_t* anchors_mask, float* box_preds, float* cls_preds, float* dir_cls_preds,
+                           float* canvas) {
+    if (!e) return PP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    const int B = e->cur_batch;
+    if (B < 1) return fail(e, PP_ERR_STATE, "pp_fetch_intermediates: nothing has run");
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const size_t HW = (size_t)e->head_h * e->head_w;
+    const int MV = e->cfg.max_voxels;
+    std::vector<int> np(B);
+    HIPCHK(e, hipMemcpy(np.data(), e->d_npillars, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (n_pillars) memcpy(n_pillars, np.data(), B * sizeof(int));
+    if (coors || num_points) {
+        std::vector<int> pcell((size_t)B * MV), pstart((size_t)B * (MV + 1));
+        HIPCHK(e, hipMemcpy(pcell.data(), e->d_pcell, pcell.size() * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(pstart.data(), e->d_pstart, pstart.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b)
+            for (int p = 0; p < np[b]; ++p) {
+                const size_t r = (size_t)b * MV + p;
+                if (coors) {
+                    const int c = pcell[r];
+                    coors[r * 3 + 0] = c / (e->nx * e->ny);
+                    coors[r * 3 + 1] = (c / e->nx) % e->ny;
+                    coors[r * 3 + 2] = c % e->nx;
+                }
+                if (num_points) {
+                    const int cnt = pstart[(size_t)b * (MV + 1) + p + 1] - pstart[(size_t)b * (MV + 1) + p];
+                    num_points[r] = cnt < e->T ? cnt : e->T;
+                }
+            }
+    }
+    if (anchors_mask) HIPCHK(e, hipMemcpy(anchors_mask, e->d_mask, (size_t)B * e->A, hipMemcpyDeviceToHost));
+    if (box_preds) HIPCHK(e, hipMemcpy(box_preds, e->d_box, (size_t)B * HW * e->napl * 7 * sizeof(float), hipMemcpyDeviceToHost));
+    if (cls_preds) HIPCHK(e, hipMemcpy(cls_preds, e->d_cls, (size_t)B * HW * e->napl * sizeof(float), hipMemcpyDeviceToHost));
+    if (dir_cls_preds) HIPCHK(e, hipMemcpy(dir_cls_preds, e->d_dir, (size_t)B * HW * e->napl * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    if (canvas) HIPCHK(e, hipMemcpy(canvas, e->d_canvas, (size_t)B * e->ny * e->nx * e->C * sizeof(float), hipMemcpyDeviceToHost));
+    return PP_OK;
+}
+
+int pp_set_profiling(pp_handle e, int32_t level) {
+    if (!e) return PP_ERR_ARG;
+    e->prof = level > 0 ? 1 : 0;
+    return PP_OK;
+}
+
+int pp_get_kernel_times(pp_handle e, int32_t capacity, const char** names, float* ms, int32_t* count) {
+    if (!e) return PP_ERR_ARG;
+    if (!count) return fail(e, PP_ERR_ARG, "pp_get_kernel_times: NULL count");
+    (void)hipSetDevice(e->device);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const int n = (int)e->ktimes.size();
+    *count = n;
+    for (int i = 0; i < n && i < capacity; ++i) {
+        float t = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&t, e->events[e->ktimes[i].ev], e->events[e->ktimes[i].ev + 1]));
+        if (names) names[i] = e->ktimes[i].name;
+        if (ms) ms[i] = t;
+    }
+    return PP_OK;
+}
+
+int pp_timer_start(pp_handle e) {
+    if (!e) return PP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    HIPCHK(e, hipEventRecord(e->t0, e->stream));
+    return PP_OK;
+}
+
+int pp_timer_stop(pp_handle e, float* elapsed_ms) {
+    if (!e) return PP_ERR_ARG;
+    if (!elapsed_ms) return fail(e, PP_ERR_ARG, "pp_timer_stop: NULL argument");
+    (void)hipSetDevice(e->device);
+    HIPCHK(e, hipEventRecord(e->t1, e->stream));
+    HIPCHK(e, hipEventSynchronize(e->t1));
+    HIPCHK(e, hipEventElapsedTime(elapsed_ms, e->t0, e->t1));
+    return PP_OK;
+}
+
+int pp_device_info(pp_handle e, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes) {
+    if (!e) return PP_ERR_ARG;
+    hipDeviceProp_t prop;
+    HIPCHK(e, hipGetDeviceProperties(&prop, e->device));
+    if (name && name_capacity > 0) {
+        snprintf(name, (size_t)name_capacity, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return PP_OK;
+}
+
+}  // extern "C"

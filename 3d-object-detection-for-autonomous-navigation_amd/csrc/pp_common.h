@@ -1,0 +1,101 @@
+// Internal declarations shared by the HIP translation units of libpp_hip.so.
+// gfx950 (MI355X / CDNA4) only: 64-wide wavefronts are assumed throughout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pp_hip.h"
+
+#define PP_WAVE 64
+
+// ----- voxel grid geometry (float64, as the reference's index math) -----
+struct VoxGeom {
+    double lo[3];   // range minimum x y z
+    double vs[3];   // voxel size x y z
+    int grid[3];    // nx ny nz = round((max-min)/vs)
+    int ncell;      // nx*ny*nz
+};
+
+// ----- one GEMM-shaped layer of the RPN ---------------------------------
+enum LayerKind { LAYER_SEP = 0, LAYER_DECONV = 1, LAYER_HEAD = 2 };
+
+struct LayerDesc {
+    int kind;
+    int cin, cout;        // channels in / out (cout of ONE tap for deconv)
+    int stride;           // depthwise stride (sep)
+    int k;                // deconv kernel == stride
+    int in_h, in_w;       // input map
+    int out_h, out_w;     // output map (sep: strided; deconv: in*k; head: in)
+    int n_total;          // GEMM N: cout (sep), k*k*cout (deconv), 32 (head, zero padded)
+    float* d_dw;          // [9][cin] depthwise taps (sep)
+    float* d_wt;          // [n_total][cin] BN-folded, transposed
+    float* d_bias;        // [cout] (sep/deconv: folded BN shift) or [32] (head)
+    const float* in;      // input activation  [B, in_h, in_w, cin]
+    float* out;           // output base
+    int ld_out;           // channels per output pixel row (row stride, floats)
+    int co_off;           // channel offset inside the output row (concat placement)
+    const char* name;
+};
+
+// ----- launchers (each in its own .hip file) ----------------------------
+void launch_cell_first(const float* pts, const int* offsets, int batch, int max_n, int F, const VoxGeom& g,
+                       int* cell, int* first, hipStream_t s);
+// returns (through *sorted_in_b) nothing; the host derives the final buffer from voxel_sort_passes()
+int voxel_sort_passes(int max_voxels);
+void launch_voxel_frame(const int* offsets, const int* cell, const int* first, int* cellmap, unsigned* keyA,
+                        unsigned* idxA, unsigned* keyB, unsigned* idxB, int* pillar_start, int* pillar_cell,
+                        int* npillars, int* nvalid, int batch, int ncell, int max_voxels, hipStream_t s);
+void launch_voxel_expand(const float* pts, const int* offsets, const unsigned* sorted_idx, const int* pillar_start,
+                         const int* pillar_cell, const int* npillars, int frame, int F, int T, int max_voxels,
+                         int ny, int nx, float* voxels, int* coors, int* num_points, hipStream_t s);
+void launch_build_cellmap(const int* coors4, int64_t P, int ncell, int ny, int nx, int* cellmap, hipStream_t s);
+
+struct PfnParams {
+    // geometry
+    int batch, nz, ny, nx, C, F, T, max_voxels;
+    float vx, vy, x_off, y_off;
+    // weights: w [Fa][C] folded, bias [C] folded
+    const float* w;
+    const float* bias;
+    // cell -> pillar map [batch][nz][ny][nx]
+    const int* cellmap;
+    // CSR source (raw points)
+    const float* pts;
+    const int* offsets;
+    const unsigned* sorted_idx;
+    const int* pillar_start;
+    // padded source (compat)
+    const float* voxels;
+    const int* num_points;
+    // outputs
+    float* canvas;    // [batch][ny][nx][C]
+    float* feat_out;  // optional [P][C]
+};
+int launch_pfn(const PfnParams& p, bool padded_source, hipStream_t s);  // returns 0 or PP_ERR_UNSUPPORTED
+
+void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, const int* cells, int64_t A,
+                        float threshold, int* integ, uint8_t* mask, hipStream_t s);
+
+int launch_layer(const LayerDesc& L, int batch, float* d_box, float* d_cls, float* d_dir, int napl,
+                 hipStream_t s);  // returns 0 or PP_ERR_UNSUPPORTED
+
+struct PostParams {
+    int batch;
+    int64_t A;
+    int pre_max, post_max;
+    float score_thr, iou_thr;
+    const float* box;      // [batch][A][7]
+    const float* cls;      // [batch][A]
+    const float* dir;      // [batch][A][2]
+    const uint8_t* mask;   // [batch][A]
+    const float* anchors;  // [A][7]
+    const float* calib;    // [batch][16]  rect @ Trv2c (float32)
+    pp_detection* dets;    // [batch][post_max]
+    int* n_dets;           // [batch]
+};
+void launch_postprocess(const PostParams& p, hipStream_t s);

@@ -1,0 +1,325 @@
+// Pillar voxelisation with the reference's exact sequential semantics, in parallel.
+//
+// Replaces points_to_voxel / _points_to_voxel_reverse_kernel
+// (reference load_data.py:695-771, :593-641): a scalar loop over the points in
+// input order in which (1) the pillar id of a cell is the order in which the
+// cell is first hit, (2) the slot of a point in its pillar is its arrival order,
+// cut at max_points, (3) the scan BREAKS when pillar number max_voxels+1 would
+// be opened, dropping every later point, and (4) the cell index is
+// floor((p - min) / voxel) evaluated in float64.
+//
+// Parallel restatement (bit-exact, deterministic -- no result depends on the
+// order in which atomics land):
+//   k_cell_first   one thread per point: float64 cell -> linear cell id (or -1);
+//                  first[cell] = min(point index) by atomicMin.
+//   k_voxel_frame  one 1024-thread workgroup per frame:
+//     A. flag = "this point is the first of its cell"; pillar id = exclusive
+//        prefix count of flags (ballot + popcount per wave, running carry);
+//        the break point is the flagged point whose prefix == max_voxels.
+//     B. stable compaction of the surviving points (cell valid, index < break)
+//        into (key = pillar id, value = point index).
+//     C. stable LSD radix sort by pillar id (<= 8 bits per pass; per-wave digit
+//        histograms in LDS; in-wave rank by digit-bit ballots), so points end
+//        up grouped by pillar in arrival order: the CSR layout the PFN reads.
+//     D. pillar_start[] from the key boundaries.
+// The padded [P,T,F] tensor of the reference is NOT materialised on the fused
+// path; k_voxel_expand produces it for the compat / parity entry point.
+//
+// Memory-bound integer work: coalesced 4-byte loads over the point axis, all
+// scratch L2-resident (a 16k-point frame moves ~1 MB).
+#include "pp_common.h"
+
+#define VT 1024
+#define VWAVES 16
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    unsigned lane = threadIdx.x & 63u;
+    return (lane == 0) ? 0ull : (~0ull >> (64u - lane));
+}
+
+__global__ __launch_bounds__(256) void k_cell_first(const float* __restrict__ pts,
+                                                    const int* __restrict__ offsets, int F, VoxGeom g,
+                                                    int* __restrict__ cell, int* __restrict__ first) {
+    const int b = blockIdx.y;
+    const int n0 = offsets[b];
+    const int n = offsets[b + 1] - n0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = pts + (size_t)(n0 + i) * F;
+    int c3[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // float32 point promoted to float64, minus float64 range, IEEE float64 divide, floor
+        double c = floor(((double)p[j] - g.lo[j]) / g.vs[j]);
+        // reference: reject if c < 0 or c >= grid.  A NaN coordinate passes that test in
+        // the reference and then indexes out of bounds (undefined); here it is rejected.
+        if (!(c >= 0.0 && c < (double)g.grid[j])) ok = false;
+        c3[j] = ok ? (int)c : 0;
+    }
+    int lin = -1;
+    if (ok) {
+        lin = (c3[2] * g.grid[1] + c3[1]) * g.grid[0] + c3[0];  // (z, y, x)
+        atomicMin(&first[(size_t)b * g.ncell + lin], i);
+    }
+    cell[n0 + i] = lin;
+}
+
+// exclusive scan of one int per thread over a 1024-thread block
+__device__ __forceinline__ int block_excl_scan(int v, int* s_tmp, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) s_tmp[wave] = x;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < VWAVES; ++w) {
+        int t = s_tmp[w];
+        if (w < wave) woff += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return woff + x - v;
+}
+
+int voxel_sort_passes(int max_voxels) {
+    int bits = 1;
+    while ((1 << bits) < max_voxels) ++bits;
+    return (bits + 7) / 8;
+}
+
+__global__ __launch_bounds__(VT) void k_voxel_frame(
+    const int* __restrict__ offsets, const int* __restrict__ cell, const int* __restrict__ first,
+    int* __restrict__ cellmap, unsigned* keyA, unsigned* idxA, unsigned* keyB, unsigned* idxB,
+    int* __restrict__ pillar_start, int* __restrict__ pillar_cell, int* __restrict__ npillars,
+    int* __restrict__ nvalid_out, int ncell, int max_voxels, int npass, int bits) {
+    __shared__ int s_tot[VWAVES];
+    __shared__ int s_carry;
+    __shared__ int s_break;
+    __shared__ int s_tmp[VWAVES];
+    __shared__ int s_hist[256 * VWAVES];
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = offsets[b];
+    const int n = offsets[b + 1] - n0;
+    const int* fcell = cell + n0;
+    const int* ffirst = first + (size_t)b * ncell;
+    int* fmap = cellmap + (size_t)b * ncell;
+    unsigned* kA = keyA + n0;
+    unsigned* vA = idxA + n0;
+    unsigned* kB = keyB + n0;
+    unsigned* vB = idxB + n0;
+    const unsigned long long lt = lanemask_lt();
+
+    if (tid == 0) { s_carry = 0; s_break = 0x7fffffff; }
+    __syncthreads();
+
+    // ---- A: pillar ids in first-appearance order, break point ----
+    for (int base = 0; base < n; base += VT) {
+        const int i = base + tid;
+        const int c = (i < n) ? fcell[i] : -1;
+        const bool flag = (c >= 0) && (ffirst[c] == i);
+        const unsigned long long bal = __ballot(flag);
+        if (lane == 0) s_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tile_tot = 0;
+#pragma unroll
+        for (int w = 0; w < VWAVES; ++w) {
+            int t = s_tot[w];
+            if (w < wave) woff += t;
+            tile_tot += t;
+        }
+        const int pid = s_carry + woff + __popcll(bal & lt);
+        if (flag) {
+            if (pid < max_voxels) {
+                fmap[c] = pid;
+                pillar_cell[(size_t)b * max_voxels + pid] = c;
+            } else if (pid == max_voxels) {
+                s_break = i;  // exactly one point has this prefix
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += tile_tot;
+    }
+    __syncthreads();
+    const int P = min(s_carry, max_voxels);
+    const int ibreak = s_break;
+    __syncthreads();
+
+    // ---- B: stable compaction of surviving points -> (pillar id, point index) ----
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += VT) {
+        const int i = base + tid;
+        const int c = (i < n) ? fcell[i] : -1;
+        const bool valid = (c >= 0) && (i < ibreak);
+        const unsigned long long bal = __ballot(valid);
+        if (lane == 0) s_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tile_tot = 0;
+#pragma unroll
+        for (int w = 0; w < VWAVES; ++w) {
+            int t = s_tot[w];
+            if (w < wave) woff += t;
+            tile_tot += t;
+        }
+        if (valid) {
+            const int pos = s_carry + woff + __popcll(bal & lt);
+            kA[pos] = (unsigned)fmap[c];
+            vA[pos] = (unsigned)i;
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += tile_tot;
+    }
+    __syncthreads();
+    const int nv = s_carry;
+    __syncthreads();
+
+    // ---- C: stable LSD radix sort by pillar id ----
+    unsigned* sk = kA; unsigned* sv = vA; unsigned* dk = kB; unsigned* dv = vB;
+    const int NB = 1 << bits;
+    const unsigned dmask = (unsigned)NB - 1u;
+    const int chunk = ((nv + VWAVES * 64 - 1) / (VWAVES * 64)) * 64;  // per-wave contiguous range
+    const int wbeg = min(wave * chunk, nv);
+    const int wend = min(wbeg + chunk, nv);
+    volatile int* vhist = s_hist;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = pass * bits;
+        for (int e = tid; e < NB * VWAVES; e += VT) s_hist[e] = 0;
+        __syncthreads();
+        for (int t0 = wbeg; t0 < wend; t0 += 64) {
+            const int j = t0 + lane;
+            if (j < wend) atomicAdd(&s_hist[((sk[j] >> shift) & dmask) * VWAVES + wave], 1);
+        }
+        __syncthreads();
+        {   // exclusive scan over (digit major, wave minor)
+            const int E = NB * VWAVES;
+            const int per = (E + VT - 1) / VT;
+            const int e0 = tid * per;
+            int local = 0;
+            for (int q = 0; q < per; ++q)
+                if (e0 + q < E) local += s_hist[e0 + q];
+            int total;
+            int run = block_excl_scan(local, s_tmp, total);
+            for (int q = 0; q < per; ++q)
+                if (e0 + q < E) { int t = s_hist[e0 + q]; s_hist[e0 + q] = run; run += t; }
+        }
+        __syncthreads();
+        for (int t0 = wbeg; t0 < wend; t0 += 64) {
+            const int j = t0 + lane;
+            const bool act = j < wend;
+            const unsigned k = act ? sk[j] : 0u;
+            const unsigned v = act ? sv[j] : 0u;
+            const unsigned d = (k >> shift) & dmask;
+            unsigned long long peers = __ballot(act);
+            for (int bit = 0; bit < bits; ++bit) {
+                const bool one = (d >> bit) & 1u;
+                const unsigned long long bb = __ballot(act && one);
+                peers &= one ? bb : ~bb;
+            }
+            if (act) {
+                const int basep = vhist[d * VWAVES + wave];
+                const int pos = basep + __popcll(peers & lt);
+                dk[pos] = k;
+                dv[pos] = v;
+                if (lane == 63 - __clzll(peers)) vhist[d * VWAVES + wave] = basep + __popcll(peers);
+            }
+        }
+        __syncthreads();
+        unsigned* t;
+        t = sk; sk = dk; dk = t;
+        t = sv; sv = dv; dv = t;
+    }
+
+    // ---- D: CSR row starts from the key boundaries ----
+    int* ps = pillar_start + (size_t)b * (max_voxels + 1);
+    for (int j = tid; j < nv; j += VT) {
+        const unsigned k = sk[j];
+        if (j == 0 || sk[j - 1] != k) ps[k] = j;
+    }
+    if (tid == 0) {
+        ps[P] = nv;
+        npillars[b] = P;
+        nvalid_out[b] = nv;
+    }
+}
+
+// compat: the reference's padded outputs for ONE frame (load_data.py:757-771)
+__global__ __launch_bounds__(64) void k_voxel_expand(const float* __restrict__ pts,
+                                                     const int* __restrict__ offsets,
+                                                     const unsigned* __restrict__ sorted_idx,
+                                                     const int* __restrict__ pillar_start,
+                                                     const int* __restrict__ pillar_cell,
+                                                     const int* __restrict__ npillars, int frame, int F, int T,
+                                                     int max_voxels, int ny, int nx, float* __restrict__ voxels,
+                                                     int* __restrict__ coors, int* __restrict__ num_points) {
+    const int p = blockIdx.x;
+    if (p >= npillars[frame]) return;
+    const int n0 = offsets[frame];
+    const int* ps = pillar_start + (size_t)frame * (max_voxels + 1);
+    const int start = ps[p];
+    const int cnt = min(ps[p + 1] - start, T);
+    const unsigned* sidx = sorted_idx + n0 + start;
+    for (int e = threadIdx.x; e < T * F; e += 64) {
+        const int s = e / F, f = e - s * F;
+        float v = 0.f;
+        if (s < cnt) v = pts[(size_t)(n0 + sidx[s]) * F + f];
+        voxels[((size_t)p * T) * F + e] = v;
+    }
+    if (threadIdx.x == 0) {
+        const int c = pillar_cell[(size_t)frame * max_voxels + p];
+        const int x = c % nx, y = (c / nx) % ny, z = c / (nx * ny);
+        coors[p * 3 + 0] = z;
+        coors[p * 3 + 1] = y;
+        coors[p * 3 + 2] = x;
+        num_points[p] = cnt;
+    }
+}
+
+// compat: cell -> pillar map from batched coors [P,4] (b z y x); validated on the host
+__global__ __launch_bounds__(256) void k_build_cellmap(const int* __restrict__ coors4, int64_t P, int ncell,
+                                                       int ny, int nx, int* __restrict__ cellmap) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int b = coors4[p * 4 + 0], z = coors4[p * 4 + 1], y = coors4[p * 4 + 2], x = coors4[p * 4 + 3];
+    cellmap[(size_t)b * ncell + ((size_t)z * ny + y) * nx + x] = (int)p;
+}
+
+void launch_cell_first(const float* pts, const int* offsets, int batch, int max_n, int F, const VoxGeom& g,
+                       int* cell, int* first, hipStream_t s) {
+    if (max_n <= 0 || batch <= 0) return;
+    dim3 grid((max_n + 255) / 256, batch);
+    hipLaunchKernelGGL(k_cell_first, grid, dim3(256), 0, s, pts, offsets, F, g, cell, first);
+}
+
+void launch_voxel_frame(const int* offsets, const int* cell, const int* first, int* cellmap, unsigned* keyA,
+                        unsigned* idxA, unsigned* keyB, unsigned* idxB, int* pillar_start, int* pillar_cell,
+                        int* npillars, int* nvalid, int batch, int ncell, int max_voxels, hipStream_t s) {
+    if (batch <= 0) return;
+    int kb = 1;
+    while ((1 << kb) < max_voxels) ++kb;
+    const int npass = (kb + 7) / 8;
+    const int bits = (kb + npass - 1) / npass;
+    hipLaunchKernelGGL(k_voxel_frame, dim3(batch), dim3(VT), 0, s, offsets, cell, first, cellmap, keyA, idxA, keyB,
+                       idxB, pillar_start, pillar_cell, npillars, nvalid, ncell, max_voxels, npass, bits);
+}
+
+void launch_voxel_expand(const float* pts, const int* offsets, const unsigned* sorted_idx, const int* pillar_start,
+                         const int* pillar_cell, const int* npillars, int frame, int F, int T, int max_voxels,
+                         int ny, int nx, float* voxels, int* coors, int* num_points, hipStream_t s) {
+    hipLaunchKernelGGL(k_voxel_expand, dim3(max_voxels), dim3(64), 0, s, pts, offsets, sorted_idx, pillar_start,
+                       pillar_cell, npillars, frame, F, T, max_voxels, ny, nx, voxels, coors, num_points);
+}
+
+void launch_build_cellmap(const int* coors4, int64_t P, int ncell, int ny, int nx, int* cellmap, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_build_cellmap, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, coors4, P, ncell, ny,
+                       nx, cellmap);
+}

@@ -1,0 +1,260 @@
+"""Engine: one handle of the HIP library per GPU, numpy in / numpy out.
+
+Thin host layer over the C-ABI (include/pp_hip.h).  Owns nothing numerical:
+every stage runs in libpp_hip.so on the GPU; a failing call raises
+RuntimeError carrying pp_last_error().
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .anchors import build_anchor_cells, build_anchors
+from .config import Derived
+from .weights import check_weights
+
+_STATUS = {1: "PP_ERR_ARG", 2: "PP_ERR_STATE", 3: "PP_ERR_HIP", 4: "PP_ERR_SHAPE", 5: "PP_ERR_UNSUPPORTED"}
+
+DET_DTYPE = np.dtype([
+    ("box3d_camera", np.float64, (7,)), ("box3d_lidar", np.float32, (7,)), ("score", np.float32),
+    ("label", np.int32), ("dir_label", np.int32), ("anchor_index", np.int32), ("reserved", np.int32)],
+    align=True)
+assert DET_DTYPE.itemsize == ctypes.sizeof(_lib.PPDetection)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Engine:
+    """config: reference-schema dict (or a config.Derived).  max_batch /
+    max_points_per_frame size the device workspaces."""
+
+    def __init__(self, config, max_batch=None, max_points_per_frame=32768, device=0, weights=None):
+        self.d = config if isinstance(config, Derived) else Derived(config)
+        d = self.d
+        self.max_batch = int(max_batch if max_batch is not None else d.batch_size)
+        self.max_points_per_frame = int(max_points_per_frame)
+        self._lib = _lib.lib()
+        c = _lib.PPConfig()
+        c.pc_range[:] = [float(v) for v in d.pc_range]
+        c.voxel_size[:] = [float(v) for v in d.voxel_size]
+        c.max_points, c.max_voxels = d.max_points, d.max_voxels
+        c.num_point_features, c.pfn_filters = d.num_point_features, d.pfn_filters
+        c.layer_nums[:] = d.layer_nums
+        c.layer_strides[:] = d.layer_strides
+        c.num_filters[:] = d.num_filters
+        c.upsample_strides[:] = d.upsample_strides
+        c.num_upsample_filters[:] = d.num_upsample_filters
+        c.num_anchor_per_loc, c.num_class = d.num_anchor_per_loc, d.num_class
+        c.nms_pre_max_size, c.nms_post_max_size = d.nms_pre_max_size, d.nms_post_max_size
+        c.nms_score_threshold, c.nms_iou_threshold = d.nms_score_threshold, d.nms_iou_threshold
+        thr = d.anchor_area_threshold
+        c.anchor_area_threshold = float(thr) if thr is not None else -1.0
+        c.max_batch, c.max_points_per_frame = self.max_batch, self.max_points_per_frame
+        h = ctypes.c_void_p()
+        st = self._lib.pp_create(ctypes.byref(c), int(device), ctypes.byref(h))
+        if st != 0:
+            msg = self._lib.pp_last_error(None)
+            raise RuntimeError(f"pp_create failed ({_STATUS.get(st, st)}): {msg.decode() if msg else ''}")
+        self._h = h
+        self.anchors = build_anchors(d)
+        self.anchor_cells = build_anchor_cells(self.anchors, d)
+        self._check(self._lib.pp_set_anchors(self._h, _ptr(self.anchors), _ptr(self.anchor_cells),
+                                             ctypes.c_int64(self.anchors.shape[0])), "pp_set_anchors")
+        self.weights_loaded = False
+        if weights is not None:
+            self.load_weights(weights)
+
+    # ---- plumbing ----
+    def _check(self, st, what):
+        if st != 0:
+            msg = self._lib.pp_last_error(self._h)
+            raise RuntimeError(f"{what} failed ({_STATUS.get(st, st)}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights (net.load_weights, train.py:731-734) ----
+    def load_weights(self, w):
+        check_weights(self.d, w)
+        for name, arr in w.items():
+            a = _f32(arr)
+            shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+            self._check(self._lib.pp_set_weight(self._h, name.encode(), _ptr(a), shape, a.ndim), f"pp_set_weight({name})")
+        self._check(self._lib.pp_finalize_weights(self._h), "pp_finalize_weights")
+        self.weights_loaded = True
+
+    # ---- a1 ----
+    def points_to_voxel(self, points):
+        d = self.d
+        points = _f32(points)
+        if points.ndim != 2 or points.shape[1] != d.num_point_features:
+            raise ValueError(f"points must be [N,{d.num_point_features}], got {points.shape}")
+        voxels = np.empty((d.max_voxels, d.max_points, d.num_point_features), dtype=np.float32)
+        coors = np.empty((d.max_voxels, 3), dtype=np.int32)
+        num = np.empty((d.max_voxels,), dtype=np.int32)
+        P = ctypes.c_int32(0)
+        self._check(self._lib.pp_points_to_voxel(self._h, _ptr(points), ctypes.c_int64(points.shape[0]),
+                                                 _ptr(voxels), _ptr(coors), _ptr(num), ctypes.byref(P)),
+                    "pp_points_to_voxel")
+        n = P.value
+        return voxels[:n].copy(), coors[:n].copy(), num[:n].copy()
+
+    # ---- a4 ----
+    def anchor_mask(self, coors4, batch):
+        coors4 = _i32(coors4).reshape(-1, 4)
+        mask = np.empty((batch, self.anchors.shape[0]), dtype=np.uint8)
+        self._check(self._lib.pp_anchor_mask(self._h, _ptr(coors4), ctypes.c_int64(coors4.shape[0]), int(batch),
+                                             _ptr(mask)), "pp_anchor_mask")
+        return mask
+
+    # ---- a5-a7, a13 ----
+    def forward_voxels(self, voxels, num_points, coors4, batch, want_features=False, want_canvas=False):
+        d = self.d
+        voxels, num_points, coors4 = _f32(voxels), _i32(num_points), _i32(coors4)
+        P = voxels.shape[0]
+        if voxels.shape[1:] != (d.max_points, d.num_point_features):
+            raise ValueError(f"voxels must be [P,{d.max_points},{d.num_point_features}], got {voxels.shape}")
+        if num_points.shape != (P,) or coors4.shape != (P, 4):
+            raise ValueError("num_points must be [P] and coors [P,4] (b,z,y,x)")
+        H, W, k = d.head_h, d.head_w, d.num_anchor_per_loc
+        box = np.empty((batch, H, W, k * 7), dtype=np.float32)
+        cls = np.empty((batch, H, W, k * d.num_class), dtype=np.float32)
+        dr = np.empty((batch, H, W, k * 2), dtype=np.float32)
+        feat = np.empty((P, d.pfn_filters), dtype=np.float32) if want_features else None
+        canvas = np.empty((batch, d.ny, d.nx, d.pfn_filters), dtype=np.float32) if want_canvas else None
+        self._check(self._lib.pp_forward_voxels(self._h, _ptr(voxels), _ptr(num_points), _ptr(coors4),
+                                                ctypes.c_int64(P), int(batch), _ptr(box), _ptr(cls), _ptr(dr),
+                                                _ptr(feat), _ptr(canvas)), "pp_forward_voxels")
+        out = {"box_preds": box, "cls_preds": cls, "dir_cls_preds": dr}
+        if want_features:
+            out["pillar_features"] = feat
+        if want_canvas:
+            out["canvas"] = canvas
+        return out
+
+    # ---- a8-a12 ----
+    def predict(self, box_preds, cls_preds, dir_cls_preds, anchors_mask, rect, trv2c):
+        batch = box_preds.shape[0]
+        post = self.d.nms_post_max_size
+        dets = np.zeros((batch, post), dtype=DET_DTYPE)
+        n = np.zeros((batch,), dtype=np.int32)
+        m = np.ascontiguousarray(anchors_mask, dtype=np.uint8).reshape(batch, -1)
+        if m.shape[1] != self.anchors.shape[0]:
+            raise ValueError(f"anchors_mask must be [batch,{self.anchors.shape[0]}]")
+        self._check(self._lib.pp_predict(self._h, _ptr(_f32(box_preds)), _ptr(_f32(cls_preds)), _ptr(_f32(dir_cls_preds)),
+                                         _ptr(m), _ptr(_f32(rect).reshape(batch, 16)), _ptr(_f32(trv2c).reshape(batch, 16)),
+                                         int(batch), _ptr(dets), _ptr(n)), "pp_predict")
+        return dets, n
+
+    # ---- fused path ----
+    @staticmethod
+    def _pack(frames, F):
+        offs = np.zeros((len(frames) + 1,), dtype=np.int32)
+        for i, f in enumerate(frames):
+            if f.ndim != 2 or f.shape[1] != F:
+                raise ValueError(f"frame {i} must be [N,{F}], got {f.shape}")
+            offs[i + 1] = offs[i] + f.shape[0]
+        pts = np.concatenate([_f32(f) for f in frames], axis=0) if frames else np.zeros((0, F), np.float32)
+        return np.ascontiguousarray(pts), offs
+
+    def upload(self, frames, rect=None, trv2c=None):
+        """frames: list of [N_b,F] float32 clouds -> engine's resident input buffer."""
+        pts, offs = self._pack(frames, self.d.num_point_features)
+        self._check(self._lib.pp_upload_points(self._h, _ptr(pts), _ptr(offs), len(frames)), "pp_upload_points")
+        if rect is not None:
+            B = len(frames)
+            self._check(self._lib.pp_set_calib(self._h, _ptr(_f32(rect).reshape(B, 16)), _ptr(_f32(trv2c).reshape(B, 16)), B),
+                        "pp_set_calib")
+        self._batch = len(frames)
+
+    def upload_device(self, dev_ptr, offsets):
+        """dev_ptr: integer device address of concatenated [sum N, F] float32 points."""
+        offs = _i32(offsets)
+        self._check(self._lib.pp_upload_points_device(self._h, ctypes.c_void_p(int(dev_ptr)), _ptr(offs), offs.shape[0] - 1),
+                    "pp_upload_points_device")
+        self._batch = offs.shape[0] - 1
+
+    def detect_async(self):
+        self._check(self._lib.pp_detect_async(self._h), "pp_detect_async")
+
+    def sync(self):
+        self._check(self._lib.pp_sync(self._h), "pp_sync")
+
+    def detections(self):
+        B, post = self._batch, self.d.nms_post_max_size
+        dets = np.zeros((B, post), dtype=DET_DTYPE)
+        n = np.zeros((B,), dtype=np.int32)
+        self._check(self._lib.pp_get_detections(self._h, _ptr(dets), _ptr(n)), "pp_get_detections")
+        return dets, n
+
+    def detect(self, frames, rect=None, trv2c=None):
+        self.upload(frames, rect, trv2c)
+        self.detect_async()
+        self.sync()
+        return self.detections()
+
+    def intermediates(self, canvas=False):
+        d, B = self.d, self._batch
+        H, W, k = d.head_h, d.head_w, d.num_anchor_per_loc
+        out = {
+            "n_pillars": np.zeros((B,), np.int32),
+            "coors": np.zeros((B, d.max_voxels, 3), np.int32),
+            "num_points": np.zeros((B, d.max_voxels), np.int32),
+            "anchors_mask": np.zeros((B, self.anchors.shape[0]), np.uint8),
+            "box_preds": np.zeros((B, H, W, k * 7), np.float32),
+            "cls_preds": np.zeros((B, H, W, k), np.float32),
+            "dir_cls_preds": np.zeros((B, H, W, k * 2), np.float32),
+        }
+        cv = np.zeros((B, d.ny, d.nx, d.pfn_filters), np.float32) if canvas else None
+        self._check(self._lib.pp_fetch_intermediates(
+            self._h, _ptr(out["n_pillars"]), _ptr(out["coors"]), _ptr(out["num_points"]), _ptr(out["anchors_mask"]),
+            _ptr(out["box_preds"]), _ptr(out["cls_preds"]), _ptr(out["dir_cls_preds"]), _ptr(cv)),
+            "pp_fetch_intermediates")
+        if canvas:
+            out["canvas"] = cv
+        return out
+
+    # ---- measurement ----
+    def set_profiling(self, on):
+        self._check(self._lib.pp_set_profiling(self._h, 1 if on else 0), "pp_set_profiling")
+
+    def kernel_times(self):
+        cap = 128
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = ctypes.c_int32(0)
+        self._check(self._lib.pp_get_kernel_times(self._h, cap, names, ms, ctypes.byref(n)), "pp_get_kernel_times")
+        return [(names[i].decode(), float(ms[i])) for i in range(min(n.value, cap))]
+
+    def timer_start(self):
+        self._check(self._lib.pp_timer_start(self._h), "pp_timer_start")
+
+    def timer_stop(self):
+        t = ctypes.c_float(0)
+        self._check(self._lib.pp_timer_stop(self._h, ctypes.byref(t)), "pp_timer_stop")
+        return float(t.value)
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        cu = ctypes.c_int32(0)
+        mem = ctypes.c_int64(0)
+        self._check(self._lib.pp_device_info(self._h, name, 256, ctypes.byref(cu), ctypes.byref(mem)), "pp_device_info")
+        return {"name": name.value.decode(), "compute_units": cu.value, "hbm_bytes": mem.value}

@@ -1,0 +1,109 @@
+"""Weight containers in the reference's Keras layouts.
+
+The released checkpoint (out/model_345/.../model_weights_48.h5) is not in the
+reference tree (.MISSING_LARGE_BLOBS) and h5py is absent, so parity is
+established with seeded synthetic weights that have NON-trivial BatchNorm
+statistics (the PFN pad constant ReLU(beta - gamma*mean/sqrt(var+eps))
+must matter).  Names / layouts (Keras):
+  pfn/dense/kernel [Fa,C]                           model/pointpillars.py:103
+  pfn/bn/{gamma,beta,moving_mean,moving_variance}   model/pointpillars.py:109
+  rpn/block{b}/{j}/depthwise_kernel [3,3,Cin,1]     model/voxelnet.py:576,584,...
+  rpn/block{b}/{j}/pointwise_kernel [1,1,Cin,Cout]
+  rpn/block{b}/{j}/bn/*
+  rpn/deconv{b}/kernel [k,k,Cout,Cin], rpn/deconv{b}/bn/*      model/voxelnet.py:591-599
+  rpn/conv_box|conv_cls|conv_dir_cls/{kernel [1,1,Cin,Cout], bias}   model/voxelnet.py:684-691
+"""
+import numpy as np
+
+BN_KEYS = ("gamma", "beta", "moving_mean", "moving_variance")
+
+
+def layer_table(d):
+    """Ordered list of (kind, name, shape-info) describing the network of config `d`."""
+    layers = []
+    cin = d.pfn_filters
+    for b in range(3):
+        cout = d.num_filters[b]
+        for j in range(d.layer_nums[b] + 1):
+            stride = d.layer_strides[b] if j == 0 else 1
+            layers.append(("sep", f"rpn/block{b + 1}/{j}", {"cin": cin, "cout": cout, "stride": stride}))
+            cin = cout
+        layers.append(("deconv", f"rpn/deconv{b + 1}",
+                       {"cin": cout, "cout": d.num_upsample_filters[b], "k": d.upsample_strides[b]}))
+    cc = d.concat_channels
+    layers.append(("head", "rpn/conv_box", {"cin": cc, "cout": d.num_anchor_per_loc * 7}))
+    layers.append(("head", "rpn/conv_cls", {"cin": cc, "cout": d.num_anchor_per_loc * d.num_class}))
+    layers.append(("head", "rpn/conv_dir_cls", {"cin": cc, "cout": d.num_anchor_per_loc * 2}))
+    return layers
+
+
+def _he_uniform(rng, shape, fan_in):
+    lim = np.sqrt(6.0 / fan_in)
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def _bn(rng, c, prefix, out):
+    out[prefix + "/gamma"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    out[prefix + "/beta"] = rng.uniform(-0.5, 0.5, c).astype(np.float32)
+    out[prefix + "/moving_mean"] = rng.uniform(-0.5, 0.5, c).astype(np.float32)
+    out[prefix + "/moving_variance"] = rng.uniform(0.5, 2.0, c).astype(np.float32)
+
+
+def init_weights(d, seed=7):
+    """Seeded synthetic weights (SURVEY section 8c/8d distributions)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    w["pfn/dense/kernel"] = _he_uniform(rng, (d.pfn_in, d.pfn_filters), d.pfn_in)
+    _bn(rng, d.pfn_filters, "pfn/bn", w)
+    for kind, name, s in layer_table(d):
+        if kind == "sep":
+            w[name + "/depthwise_kernel"] = _he_uniform(rng, (3, 3, s["cin"], 1), 9)
+            w[name + "/pointwise_kernel"] = _he_uniform(rng, (1, 1, s["cin"], s["cout"]), s["cin"])
+            _bn(rng, s["cout"], name + "/bn", w)
+        elif kind == "deconv":
+            k = s["k"]
+            w[name + "/kernel"] = _he_uniform(rng, (k, k, s["cout"], s["cin"]), s["cin"])
+            _bn(rng, s["cout"], name + "/bn", w)
+        else:
+            w[name + "/kernel"] = _he_uniform(rng, (1, 1, s["cin"], s["cout"]), s["cin"])
+            w[name + "/bias"] = rng.uniform(-0.1, 0.1, s["cout"]).astype(np.float32)
+    return w
+
+
+def expected_shapes(d):
+    shapes = {"pfn/dense/kernel": (d.pfn_in, d.pfn_filters)}
+    for k in BN_KEYS:
+        shapes["pfn/bn/" + k] = (d.pfn_filters,)
+    for kind, name, s in layer_table(d):
+        if kind == "sep":
+            shapes[name + "/depthwise_kernel"] = (3, 3, s["cin"], 1)
+            shapes[name + "/pointwise_kernel"] = (1, 1, s["cin"], s["cout"])
+            for k in BN_KEYS:
+                shapes[name + "/bn/" + k] = (s["cout"],)
+        elif kind == "deconv":
+            shapes[name + "/kernel"] = (s["k"], s["k"], s["cout"], s["cin"])
+            for k in BN_KEYS:
+                shapes[name + "/bn/" + k] = (s["cout"],)
+        else:
+            shapes[name + "/kernel"] = (1, 1, s["cin"], s["cout"])
+            shapes[name + "/bias"] = (s["cout"],)
+    return shapes
+
+
+def check_weights(d, w):
+    """Raises ValueError on a missing / mis-shaped tensor (the reference's
+    net.load_weights raises on a layout mismatch too, train.py:731-734)."""
+    for name, shp in expected_shapes(d).items():
+        if name not in w:
+            raise ValueError(f"missing weight tensor {name!r}")
+        if tuple(w[name].shape) != tuple(shp):
+            raise ValueError(f"weight {name!r}: shape {tuple(w[name].shape)} != expected {tuple(shp)}")
+
+
+def save_npz(path, w):
+    np.savez(path, **{k.replace("/", "."): v for k, v in w.items()})
+
+
+def load_npz(path):
+    with np.load(path) as z:
+        return {k.replace(".", "/"): np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}

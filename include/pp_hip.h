@@ -1,0 +1,192 @@
+/* pp_hip.h -- C-ABI of the MI355X-native PointPillars inference path (libpp_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of
+ * krullgit/3D-Object-Detection-for-autonomous-navigation's `train.py evaluate`
+ * (reference paths below are relative to that repository).  The reference has
+ * no FFI for this path -- its callers are Python call sites
+ * -- so each entry point names the Python interface it replaces; the binding a
+ * maintainer adds on the reference side is the ctypes stub in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no framework types.  Every pointer is a
+ *     HOST pointer unless its parameter is documented "device pointer".
+ *   - integer status codes (PP_OK == 0); no exceptions cross the ABI; the text
+ *     of the last failure is returned by pp_last_error().
+ *   - one handle per GPU; a handle is not thread-safe; distinct handles are
+ *     fully independent (own stream, own device workspaces sized at create
+ *     for max_batch x max_points_per_frame).
+ *   - every compute entry point runs on the GPU (gfx950).  There is no CPU
+ *     fallback: without a device, pp_create fails.
+ */
+#ifndef PP_HIP_H
+#define PP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_ABI_VERSION 1
+
+enum pp_status {
+    PP_OK = 0,
+    PP_ERR_ARG = 1,    /* null / out-of-range argument */
+    PP_ERR_STATE = 2,  /* call order: weights or anchors not set */
+    PP_ERR_HIP = 3,    /* a HIP runtime call failed (see pp_last_error) */
+    PP_ERR_SHAPE = 4,  /* tensor shape does not match the configuration */
+    PP_ERR_UNSUPPORTED = 5
+};
+
+typedef struct pp_engine* pp_handle;
+
+/* Mirrors the keys the reference's hot path reads from configs/train.yaml
+ * (SURVEY.md section 5 "Config / flag system"; values of the shipped config in
+ * SURVEY Appendix B). */
+typedef struct pp_config {
+    double pc_range[6];   /* model.second.voxel_generator.point_cloud_range: xmin ymin zmin xmax ymax zmax */
+    double voxel_size[3]; /* ...voxel_size (float64, as load_data.py:2573-2574 builds them) */
+    int32_t max_points;   /* ...max_number_of_points_per_voxel  (T) */
+    int32_t max_voxels;   /* ...max_number_of_voxels */
+    int32_t num_point_features; /* model.second.num_point_features (F: 3 or 4) */
+    int32_t pfn_filters;  /* voxel_feature_extractor.num_filters (C) */
+    int32_t layer_nums[3];            /* rpn.layer_nums */
+    int32_t layer_strides[3];         /* rpn.layer_strides */
+    int32_t num_filters[3];           /* rpn.num_filters */
+    int32_t upsample_strides[3];      /* rpn.upsample_strides */
+    int32_t num_upsample_filters[3];  /* rpn.num_upsample_filters */
+    int32_t num_anchor_per_loc;       /* len(rotations) * len(sizes) */
+    int32_t num_class;                /* model.second.num_class (1) */
+    int32_t nms_pre_max_size;         /* model.second.nms_pre_max_size */
+    int32_t nms_post_max_size;        /* model.second.nms_post_max_size */
+    float nms_score_threshold;        /* model.second.nms_score_threshold */
+    float nms_iou_threshold;          /* model.second.nms_iou_threshold */
+    float anchor_area_threshold;      /* eval_input_reader.anchor_area_threshold */
+    int32_t max_batch;                /* frames per call the workspaces are sized for */
+    int32_t max_points_per_frame;     /* points per frame the workspaces are sized for */
+} pp_config;
+
+/* One detection, in NMS keep order (descending score), as VoxelNet.predict
+ * assembles it (model/voxelnet.py:1281-1369). */
+typedef struct pp_detection {
+    double box3d_camera[7]; /* x y z l h w r, float64 as box_lidar_to_camera returns (eval_helper_functions.py:735-740) */
+    float box3d_lidar[7];   /* x y z w l h r after the direction flip (model/voxelnet.py:1305-1310) */
+    float score;            /* sigmoid(cls) (model/voxelnet.py:1150) */
+    int32_t label;          /* label_preds (always 0: one class) */
+    int32_t dir_label;      /* argmax of the direction head */
+    int32_t anchor_index;   /* flat anchor index (y, x, rot) of the source anchor */
+    int32_t reserved;
+} pp_detection;
+
+/* ---- lifetime -------------------------------------------------------- */
+
+/* Replaces VoxelNet.__init__ (model/voxelnet.py:727-787) + the dataloader's
+ * per-config constants.  Fails with PP_ERR_HIP when no gfx950 device `device`
+ * is usable. */
+int pp_create(const pp_config* cfg, int device, pp_handle* out);
+int pp_destroy(pp_handle h);
+/* Text of the last failure on `h` (or of the last pp_create failure when h is NULL). */
+const char* pp_last_error(pp_handle h);
+int pp_abi_version(void);
+
+/* ---- weights: replaces net.load_weights (train.py:731-734) ------------ */
+
+/* One named float32 tensor in the Keras layout (names / layouts listed in
+ * INTEGRATION.md and <package>/weights.py).  The data is copied. */
+int pp_set_weight(pp_handle h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+/* Verifies that every tensor is present, folds BatchNorm (eps 1e-3) into the
+ * following GEMM and uploads the kernel-side layouts. */
+int pp_finalize_weights(pp_handle h);
+
+/* Static anchors [A,7] (x y z w l h r) in the reference's (y, x, rot) order and
+ * their clamped integral-image cells [A,4] (x0 y0 x1 y1), built once on the
+ * host (replaces the per-frame generate_anchors / rbbox2d_to_near_bbox calls,
+ * load_data.py:3029-3043). */
+int pp_set_anchors(pp_handle h, const float* anchors, const int32_t* cells, int64_t num_anchors);
+
+/* ---- stage entry points (parity checkpoints) -------------------------- */
+
+/* points_to_voxel(points, voxel_size, coors_range, max_points, True, max_voxels)
+ * (load_data.py:695-771) for ONE frame of n points [n,F].  Outputs are sized
+ * by the caller for max_voxels pillars: voxels [max_voxels,T,F] (only the
+ * first *n_pillars rows are written, zero padded), coors [max_voxels,3] (z y x),
+ * num_points [max_voxels]. */
+int pp_points_to_voxel(pp_handle h, const float* points, int64_t n, float* voxels, int32_t* coors,
+                       int32_t* num_points, int32_t* n_pillars);
+
+/* The dataloader's anchors_mask for `batch` frames (load_data.py:3043-3072)
+ * from batched pillar coordinates coors [P,4] (b z y x).  mask [batch,A] u8. */
+int pp_anchor_mask(pp_handle h, const int32_t* coors, int64_t num_pillars, int32_t batch, uint8_t* mask);
+
+/* VoxelNet.__call__(voxels, num_points, coors, batch_anchors) eval branch
+ * (model/voxelnet.py:850-916): voxels [P,T,F], num_points [P], coors [P,4]
+ * (b z y x, unique per frame as points_to_voxel produces them).  Outputs NHWC:
+ * box_preds [batch,H',W',2*7], cls_preds [batch,H',W',2], dir_cls_preds
+ * [batch,H',W',4].  Optional checkpoints (may be NULL): pillar_features [P,C]
+ * (PillarFeatureNet output) and canvas [batch,ny,nx,C] (PointPillarsScatter
+ * output, NHWC). */
+int pp_forward_voxels(pp_handle h, const float* voxels, const int32_t* num_points, const int32_t* coors,
+                      int64_t num_pillars, int32_t batch, float* box_preds, float* cls_preds,
+                      float* dir_cls_preds, float* pillar_features, float* canvas);
+
+/* VoxelNet.predict(example, preds_dict) (model/voxelnet.py:1060-1390) on the
+ * head maps.  anchors_mask [batch,A] u8; rect, trv2c [batch,16] row-major 4x4.
+ * dets [batch * nms_post_max_size]; n_dets [batch] (0 == the reference's
+ * all-None dict). */
+int pp_predict(pp_handle h, const float* box_preds, const float* cls_preds, const float* dir_cls_preds,
+               const uint8_t* anchors_mask, const float* rect, const float* trv2c, int32_t batch,
+               pp_detection* dets, int32_t* n_dets);
+
+/* ---- fused path: raw points -> detections ----------------------------- */
+
+/* Copies `batch` frames of raw points into the engine's device input buffer.
+ * points: concatenated [sum n_b, F]; frame_offsets [batch+1] (row offsets). */
+int pp_upload_points(pp_handle h, const float* points, const int32_t* frame_offsets, int32_t batch);
+/* Same, from a DEVICE pointer `points_dev` (device-to-device copy on the engine's stream). */
+int pp_upload_points_device(pp_handle h, const void* points_dev, const int32_t* frame_offsets, int32_t batch);
+/* Calibration for the uploaded frames: rect, trv2c [batch,16]. */
+int pp_set_calib(pp_handle h, const float* rect, const float* trv2c, int32_t batch);
+
+/* Enqueues the whole path (a1..a12 of SURVEY section 8a) for the frames resident in
+ * the engine's input buffer on the engine's stream: voxelise -> PFN + scatter
+ * -> anchor mask -> backbone + heads -> top-k / decode / NMS -> detections in
+ * device memory, then an async copy into the engine's pinned result buffer.
+ * Returns without waiting. */
+int pp_detect_async(pp_handle h);
+/* Waits for the engine's stream. */
+int pp_sync(pp_handle h);
+/* After pp_sync: copies the last results.  dets [batch*nms_post_max_size], n_dets [batch]. */
+int pp_get_detections(pp_handle h, pp_detection* dets, int32_t* n_dets);
+/* Convenience: upload + calib + detect + sync + get (the evaluate loop body,
+ * train.py:689-786 minus annotation formatting). */
+int pp_detect(pp_handle h, const float* points, const int32_t* frame_offsets, int32_t batch,
+              const float* rect, const float* trv2c, pp_detection* dets, int32_t* n_dets);
+
+/* Debug / parity taps of the fused path (after pp_sync), any pointer may be
+ * NULL: per-frame pillar counts [batch]; coors [batch*max_voxels,3];
+ * num_points [batch*max_voxels]; anchors mask [batch,A]; head maps as in
+ * pp_forward_voxels; canvas [batch,ny,nx,C]. */
+int pp_fetch_intermediates(pp_handle h, int32_t* n_pillars, int32_t* coors, int32_t* num_points,
+                           uint8_t* anchors_mask, float* box_preds, float* cls_preds,
+                           float* dir_cls_preds, float* canvas);
+
+/* ---- measurement ------------------------------------------------------ */
+
+/* level 0: no events.  level 1: HIP events on the engine's stream around
+ * every kernel launch of pp_detect_async (for bench.py's roofline leg). */
+int pp_set_profiling(pp_handle h, int32_t level);
+/* After pp_sync with profiling on: number of timed kernel launches of the last
+ * pp_detect_async, their names and durations (ms).  Buffers sized by the
+ * caller for `capacity` entries; names are static strings. */
+int pp_get_kernel_times(pp_handle h, int32_t capacity, const char** names, float* ms, int32_t* count);
+/* HIP-event stopwatch on the engine's stream. */
+int pp_timer_start(pp_handle h);
+int pp_timer_stop(pp_handle h, float* elapsed_ms); /* records, waits, returns the elapsed time */
+
+/* Device properties for reports: name (<=255 chars), CU count, bytes of HBM. */
+int pp_device_info(pp_handle h, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PP_HIP_H */

@@ -1,0 +1,308 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle and the golden fixtures.
+
+All tests here need a real MI355X (`-m gpu`).  Tolerances: integer / index work
+is bit-exact; floating point within 1e-4 (north_star), most stages far tighter.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import c_oracle, nn_ref, ref_numpy as rn
+import util_ref
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _cfg(pp, case):
+    c = pp.config
+    if case == "kitti5k":
+        return c.kitti_shaped_config()
+    if case == "tiny":
+        return c.tiny_config()
+    return c.pedestrian_d435i_config()
+
+
+@pytest.fixture(scope="module")
+def engines(pp, hip_lib):
+    cache = {}
+
+    def get(name, cfg, max_batch=1, nmax=32768, weights_seed=None):
+        key = (name, max_batch, nmax)
+        if key not in cache:
+            eng = pp.Engine(cfg, max_batch=max_batch, max_points_per_frame=nmax)
+            if weights_seed is not None:
+                eng.load_weights(util_ref.scale_heads(pp.weights.init_weights(eng.d, seed=weights_seed)))
+            cache[key] = eng
+        return cache[key]
+
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+# ------------------------------------------------------------------ a1
+@pytest.mark.parametrize("case", ["a2k", "a16k", "brk", "t100", "kitti5k", "tiny"])
+def test_voxelise_matches_reference_golden(pp, engines, case):
+    g = load_golden("ref_voxel.npz")
+    T, MV = (int(v) for v in g[case + "_params"])
+    cfg = _cfg(pp, case)
+    cfg["model"]["second"]["voxel_generator"].update(max_number_of_points_per_voxel=T, max_number_of_voxels=MV)
+    eng = engines(f"vox-{case}", cfg)
+    v, c, n = eng.points_to_voxel(g[case + "_points"])
+    assert np.array_equal(c, g[case + "_coors"]), "pillar coordinates / order must be bit-exact"
+    assert np.array_equal(n, g[case + "_num"])
+    assert np.array_equal(v, g[case + "_voxels"])
+
+
+def test_points_to_voxel_reference_signature(pp, hip_lib):
+    g = load_golden("ref_voxel.npz")
+    d = pp.config.Derived(pp.config.pedestrian_d435i_config())
+    v, c, n = pp.points_to_voxel(g["a2k_points"], d.voxel_size, d.pc_range, 50, True, 12000)
+    assert np.array_equal(c, g["a2k_coors"]) and np.array_equal(n, g["a2k_num"]) and np.array_equal(v, g["a2k_voxels"])
+    with pytest.raises(NotImplementedError):
+        pp.points_to_voxel(g["a2k_points"], d.voxel_size, d.pc_range, 50, False, 12000)
+
+
+def test_voxelise_edge_cases(pp, engines):
+    eng = engines("vox-a2k", _cfg(pp, "a2k"))
+    d = eng.d
+    for pts in (np.zeros((0, 3), np.float32),                       # empty
+                np.full((7, 3), 100.0, np.float32),                 # everything out of range
+                np.array([[1.0, 0.0, 0.0]], np.float32),            # one point
+                np.tile(np.array([[2.0, 0.5, 0.1]], np.float32), (300, 1)),  # 300 duplicates > T
+                np.array([[np.nan, 0, 0], [1, 0, 0], [np.inf, 0, 0], [1, -np.inf, 0]], np.float32)):
+        v, c, n = eng.points_to_voxel(pts)
+        finite = pts[np.isfinite(pts).all(axis=1)] if pts.size else pts
+        ve, ce, ne = c_oracle.points_to_voxel(finite, d.voxel_size, d.pc_range, d.max_points, d.max_voxels)
+        assert np.array_equal(c, ce) and np.array_equal(n, ne) and np.array_equal(v, ve)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_voxelise_16k_vs_oracle(pp, engines, seed):
+    eng = engines("vox-a2k", _cfg(pp, "a2k"))
+    d = eng.d
+    pts = pp.synth.d435i_cloud(100 + seed)
+    v, c, n = eng.points_to_voxel(pts)
+    ve, ce, ne = c_oracle.points_to_voxel(pts, d.voxel_size, d.pc_range, d.max_points, d.max_voxels)
+    assert np.array_equal(c, ce) and np.array_equal(n, ne) and np.array_equal(v, ve)
+
+
+def test_voxelise_max_voxels_break_at_scale(pp, engines):
+    cfg = pp.config.pedestrian_d435i_config(max_points=10, max_voxels=1000)
+    eng = engines("vox-break1000", cfg)
+    d = eng.d
+    pts = pp.synth.d435i_cloud(7)
+    v, c, n = eng.points_to_voxel(pts)
+    ve, ce, ne = c_oracle.points_to_voxel(pts, d.voxel_size, d.pc_range, 10, 1000)
+    assert v.shape[0] == 1000
+    assert np.array_equal(c, ce) and np.array_equal(n, ne) and np.array_equal(v, ve)
+
+
+# ------------------------------------------------------------------ a4
+@pytest.mark.parametrize("case", ["a2k", "a16k"])
+def test_anchor_mask_matches_reference_golden(pp, engines, case):
+    gv, gm = load_golden("ref_voxel.npz"), load_golden("ref_mask.npz")
+    eng = engines("vox-a2k", _cfg(pp, "a2k"))
+    c = gv[case + "_coors"]
+    c4 = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], axis=1)
+    m = eng.anchor_mask(c4, 1)[0].astype(bool)
+    assert np.array_equal(m, gm[case + "_mask"])
+
+
+# ------------------------------------------------------------------ a5-a7, a13
+@pytest.mark.parametrize("name,nframes,npts", [("tiny", 2, 600), ("A", 2, 16384)])
+def test_forward_matches_oracle(pp, engines, name, nframes, npts):
+    cfg = pp.config.tiny_config(nframes) if name == "tiny" else pp.config.pedestrian_d435i_config(nframes)
+    eng = engines(f"net-{name}", cfg, max_batch=nframes, weights_seed=7)
+    d = eng.d
+    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=7))
+    if name == "tiny":
+        rng = np.random.default_rng(9)
+        frames = [rng.uniform([0, -0.64, -3], [1.6, 0.64, 3], (npts, 3)).astype(np.float32) for _ in range(nframes)]
+    else:
+        frames = [pp.synth.d435i_cloud(20 + i, npts) for i in range(nframes)]
+    rect, trv, p2 = pp.synth.default_calib()
+    ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
+    ex = ref["example"]
+    out = eng.forward_voxels(ex[0], ex[1], ex[2], nframes, want_features=True, want_canvas=True)
+    np.testing.assert_allclose(out["pillar_features"], ref["features"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(out["canvas"], ref["canvas"], rtol=1e-5, atol=1e-5)
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        assert out[k].shape == ref["preds"][k].shape
+        np.testing.assert_allclose(out[k], ref["preds"][k], rtol=TOL, atol=TOL)
+    # shared (y, x) across z-cells must have been summed (tf.scatter_nd semantics)
+    yx = ex[2][:, 0] * 10**6 + ex[2][:, 2] * 1000 + ex[2][:, 3]
+    if name == "A":
+        assert len(np.unique(yx)) < len(yx)
+
+
+# ------------------------------------------------------------------ a8-a12
+def _assert_dets(pp_dicts, ref_dicts):
+    assert len(pp_dicts) == len(ref_dicts)
+    for a, b in zip(pp_dicts, ref_dicts):
+        if b["scores"] is None:
+            assert a["scores"] is None and a["box3d_lidar"] is None and a["bbox"] is None
+            continue
+        assert a["scores"] is not None
+        assert a["scores"].shape == b["scores"].shape
+        np.testing.assert_allclose(a["scores"], b["scores"], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(a["box3d_lidar"], b["box3d_lidar"], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(a["box3d_camera"], b["box3d_camera"], rtol=TOL, atol=TOL)
+        assert a["box3d_camera"].dtype == np.float64 and a["box3d_lidar"].dtype == np.float32
+        assert np.array_equal(a["label_preds"], b["label_preds"])
+        assert np.array_equal(a["bbox"], b["bbox"])
+
+
+def test_predict_matches_oracle_on_oracle_preds(pp, hip_lib):
+    """VoxelNet.predict surface on head maps computed by the oracle (isolates a8-a12)."""
+    cfg = pp.config.pedestrian_d435i_config(2)
+    net = pp.VoxelNet(cfg, None, training=False, max_batch=2)
+    d = net.d
+    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=7))
+    net.load_weights(w)
+    frames = [pp.synth.d435i_cloud(40 + i) for i in range(2)]
+    rect, trv, p2 = pp.synth.default_calib()
+    ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
+    got = net.predict(ref["example"], ref["preds"])
+    assert all(r["scores"] is not None and len(r["scores"]) >= 2 for r in ref["dets"]), "fixture must produce detections"
+    _assert_dets(got, ref["dets"])
+    # empty mask -> the reference's all-None dict
+    ex = list(ref["example"])
+    ex[7] = np.zeros_like(ex[7])
+    got = net.predict(tuple(ex), ref["preds"])
+    assert all(g["scores"] is None and g["batch_idx"] == i for i, g in enumerate(got))
+    net.engine.close()
+
+
+def test_predict_nms_conventions(pp, engines):
+    """Hand-built head maps: +1 IoU in metre space, strict >, pre/post caps, direction flip."""
+    eng = engines("net-A1", pp.config.pedestrian_d435i_config(1), max_batch=1)
+    d = eng.d
+    A = d.num_anchors
+    box = np.zeros((1, d.head_h, d.head_w, 14), np.float32)
+    cls = np.full((1, d.head_h, d.head_w, 2), -9.0, np.float32)
+    dr = np.zeros((1, d.head_h, d.head_w, 4), np.float32)
+    mask = np.zeros((1, A), np.uint8)   # only the hand-placed anchors are candidates (no score ties)
+    # three anchors: two 0.4 m apart (suppressed by the +1 convention), one 3 m away
+    for (y, x, r, logit, dirbin) in ((10, 10, 0, 3.0, 1), (10, 15, 0, 2.0, 0), (40, 50, 1, 1.0, 1)):
+        cls[0, y, x, r] = logit
+        dr[0, y, x, 2 * r + dirbin] = 1.0
+        mask[0, (y * d.head_w + x) * 2 + r] = 1
+    rect, trv, _ = pp.synth.default_calib()
+    dets, n = eng.predict(box, cls, dr, mask, rect[None], trv[None])
+    ex = (None, None, None, rect[None], trv[None], None, eng.anchors[None], mask, np.array([0]), None)
+    ref = rn.predict(ex, {"box_preds": box, "cls_preds": cls, "dir_cls_preds": dr}, d.nms_dict())[0]
+    assert n[0] == len(ref["scores"])
+    np.testing.assert_allclose(dets[0]["score"][:n[0]], ref["scores"], rtol=1e-6)
+    np.testing.assert_allclose(dets[0]["box3d_lidar"][:n[0]], ref["box3d_lidar"], rtol=1e-6, atol=1e-6)
+    a0 = (10 * d.head_w + 10) * 2
+    assert dets[0]["anchor_index"][0] == a0 and dets[0]["dir_label"][0] == 1
+    kept = set(int(v) for v in dets[0]["anchor_index"][:n[0]])
+    assert (10 * d.head_w + 15) * 2 not in kept, "0.4 m apart must be suppressed by the +1 IoU"
+    assert (40 * d.head_w + 50) * 2 + 1 in kept
+
+
+# ------------------------------------------------------------------ fused path, end to end
+@pytest.mark.parametrize("name", ["tiny", "A"])
+def test_fused_detect_matches_oracle_end_to_end(pp, engines, name):
+    B = 3
+    cfg = pp.config.tiny_config(B) if name == "tiny" else pp.config.pedestrian_d435i_config(B)
+    eng = engines(f"net-{name}", cfg, max_batch=B, weights_seed=7)
+    d = eng.d
+    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=7))
+    if name == "tiny":
+        rng = np.random.default_rng(19)
+        frames = [rng.uniform([0, -0.64, -3], [1.6, 0.64, 3], (n, 3)).astype(np.float32) for n in (700, 0, 333)]
+    else:
+        frames = [pp.synth.d435i_cloud(60, 16384), pp.synth.d435i_cloud(61, 9000), pp.synth.d435i_cloud(62, 16384)]
+    rect, trv, p2 = pp.synth.default_calib()
+    ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
+    dets, n = eng.detect(frames, np.stack([rect] * B), np.stack([trv] * B))
+    im = eng.intermediates(canvas=True)
+    for b in range(B):
+        fr = ref["frames"][b]
+        P = fr["coordinates"].shape[0]
+        assert im["n_pillars"][b] == P
+        assert np.array_equal(im["coors"][b, :P], fr["coordinates"])
+        assert np.array_equal(im["num_points"][b, :P], fr["num_points"])
+        assert np.array_equal(im["anchors_mask"][b].astype(bool), fr["anchors_mask"])
+    np.testing.assert_allclose(im["canvas"], ref["canvas"], rtol=1e-5, atol=1e-5)
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=TOL, atol=TOL)
+    from importlib import import_module
+    to_dict = pp.VoxelNet._to_dict
+    got = [to_dict(dets[b], int(n[b]), b) for b in range(B)]
+    _assert_dets(got, ref["dets"])
+
+
+# ------------------------------------------------------------------ size-independent properties at full batch
+def test_full_batch_properties(pp, engines):
+    B = 64
+    eng = engines("net-A64", pp.config.pedestrian_d435i_config(B), max_batch=B, weights_seed=7)
+    frames = [pp.synth.d435i_cloud(200 + i) for i in range(B)]
+    dets1, n1 = eng.detect(frames)
+    im1 = eng.intermediates()
+    dets2, n2 = eng.detect(frames)
+    assert np.array_equal(n1, n2) and dets1.tobytes() == dets2.tobytes(), "bit-reproducible"
+    # a frame's result does not depend on its batch neighbours or its slot
+    perm = np.random.default_rng(0).permutation(B)
+    dets3, n3 = eng.detect([frames[i] for i in perm])
+    for slot, i in enumerate(perm):
+        assert n3[slot] == n1[i]
+        assert dets3[slot, :n3[slot]].tobytes() == dets1[i, :n1[i]].tobytes()
+    for b in range(B):
+        k = int(n1[b])
+        assert 0 <= k <= eng.d.nms_post_max_size
+        s = dets1[b]["score"][:k]
+        assert (np.diff(s) <= 0).all(), "keep order is descending score"
+        assert ((s > 0) & (s < 1)).all()
+        # NMS is idempotent: survivors do not suppress each other (AABB +1 IoU <= 0.5)
+        P = im1["n_pillars"][b]
+        assert 0 < P <= eng.d.max_voxels
+        assert im1["num_points"][b, :P].min() >= 1 and im1["num_points"][b, :P].max() <= eng.d.max_points
+        flat = (im1["coors"][b, :P, 0] * eng.d.ny + im1["coors"][b, :P, 1]) * eng.d.nx + im1["coors"][b, :P, 2]
+        assert len(np.unique(flat)) == P, "one pillar per cell"
+    # pillar point budget: sum(min(count, T)) over pillars == points kept by the oracle for a sampled frame
+    d = eng.d
+    ve, ce, ne = c_oracle.points_to_voxel(frames[5], d.voxel_size, d.pc_range, d.max_points, d.max_voxels)
+    assert np.array_equal(im1["coors"][5, :len(ce)], ce) and np.array_equal(im1["num_points"][5, :len(ne)], ne)
+
+
+def test_kitti_shaped_forward(pp, engines):
+    """cfg-K (496x432 BEV, F=4, C=64, T=100): voxelise + mask bit-exact, head maps within 1e-4."""
+    B = 1
+    eng = engines("net-K", pp.config.kitti_shaped_config(B), max_batch=B, weights_seed=5)
+    d = eng.d
+    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=5))
+    frames = [pp.synth.kitti_cloud(3)]
+    rect, trv, p2 = pp.synth.default_calib()
+    ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
+    dets, n = eng.detect(frames, rect[None], trv[None])
+    im = eng.intermediates()
+    fr = ref["frames"][0]
+    P = fr["coordinates"].shape[0]
+    assert im["n_pillars"][0] == P and np.array_equal(im["coors"][0, :P], fr["coordinates"])
+    assert np.array_equal(im["anchors_mask"][0].astype(bool), fr["anchors_mask"])
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=TOL, atol=TOL)
+    got = [pp.VoxelNet._to_dict(dets[0], int(n[0]), 0)]
+    _assert_dets(got, ref["dets"])
+
+
+def test_error_behaviour(pp, engines):
+    eng = engines("net-tiny-err", pp.config.tiny_config(1), max_batch=1)
+    with pytest.raises(RuntimeError, match="weights"):
+        eng.detect([np.zeros((4, 3), np.float32)])
+    with pytest.raises(ValueError):
+        eng.points_to_voxel(np.zeros((4, 4), np.float32))
+    with pytest.raises(RuntimeError, match="batch"):
+        eng.detect([np.zeros((4, 3), np.float32)] * 2)
+    bad = np.array([[0, 0, 99, 0]], np.int32)
+    with pytest.raises(RuntimeError, match="outside"):
+        eng.anchor_mask(bad, 1)
+    w = pp.weights.init_weights(eng.d, seed=1)
+    w["rpn/conv_box/kernel"] = w["rpn/conv_box/kernel"][..., :7]
+    with pytest.raises(ValueError):
+        eng.load_weights(w)
