@@ -224,6 +224,12 @@ static void launch_t(const GemmArgs& a, int n_total, hipStream_t s) {
     hipLaunchKernelGGL((k_gemm_layer<NT, MODE>), grid, dim3(256), 0, s, a);
 }
 
+const char* layer_kernel_name(const LayerDesc& L) {
+    const int nt = (L.kind == LAYER_HEAD) ? 32 : (L.cout % 128 == 0 ? 128 : (L.cout % 64 == 0 ? 64 : 32));
+    if (L.kind == LAYER_SEP) return nt == 128 ? "k_gemm_layer<128,0>" : (nt == 64 ? "k_gemm_layer<64,0>" : "k_gemm_layer<32,0>");
+    return nt == 128 ? "k_gemm_layer<128,1>" : (nt == 64 ? "k_gemm_layer<64,1>" : "k_gemm_layer<32,1>");
+}
+
 int launch_layer(const LayerDesc& L, int batch, float* d_box, float* d_cls, float* d_dir, int napl,
                  hipStream_t s) {
     if (batch <= 0) return 0;

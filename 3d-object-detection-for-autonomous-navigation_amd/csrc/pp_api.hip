@@ -60,6 +60,7 @@ struct pp_engine {
     pp_detection* h_dets = nullptr;  // pinned
     int* h_ndets = nullptr;          // pinned
     std::vector<LayerDesc> layers;
+    std::vector<std::string> layer_tags;  // "<kernel symbol>:<layer>" for the profiler
 
     // compat scratch (grow-only)
     float* d_voxels = nullptr; size_t cap_voxels = 0;
@@ -237,7 +238,7 @@ int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out) {
     p.pts = e->d_points; p.offsets = e->d_offsets; p.sorted_idx = sorted_idx(e); p.pillar_start = e->d_pstart;
     p.voxels = e->d_voxels; p.num_points = e->d_numpts;
     p.canvas = e->d_canvas; p.feat_out = feat_out;
-    ProfScope ps(e, "k_pfn_canvas");
+    ProfScope ps(e, "k_pfn_canvas:pfn+scatter");
     int st = launch_pfn(p, padded, e->stream);
     if (st) return fail(e, st, "PFN: unsupported C=%d / F=%d", e->C, e->F);
     HIPCHK(e, hipGetLastError());
@@ -245,7 +246,7 @@ int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out) {
 }
 
 int run_anchor_mask(pp_engine* e, int batch) {
-    ProfScope ps(e, "anchor_mask(3 kernels)");
+    ProfScope ps(e, "anchor_mask:rowscan+colscan+lookup");
     launch_anchor_mask(e->d_cellmap, batch, e->nz, e->ny, e->nx, e->d_cells, e->A, e->cfg.anchor_area_threshold,
                        e->d_integ, e->d_mask, e->stream);
     HIPCHK(e, hipGetLastError());
@@ -253,8 +254,9 @@ int run_anchor_mask(pp_engine* e, int batch) {
 }
 
 int run_backbone(pp_engine* e, int batch) {
-    for (const LayerDesc& L : e->layers) {
-        ProfScope ps(e, L.name);
+    for (size_t i = 0; i < e->layers.size(); ++i) {
+        const LayerDesc& L = e->layers[i];
+        ProfScope ps(e, e->layer_tags[i].c_str());
         int st = launch_layer(L, batch, e->d_box, e->d_cls, e->d_dir, e->napl, e->stream);
         if (st) return fail(e, st, "layer %s: unsupported shape (cin=%d cout=%d)", L.name, L.cin, L.cout);
     }
@@ -449,6 +451,7 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
         }
         // wire activation buffers: ping-pong inside the blocks, deconvs into the concat buffer
         if (st2 == PP_OK) {
+            for (const LayerDesc& L : e->layers) e->layer_tags.push_back(std::string(layer_kernel_name(L)) + ":" + L.name);
             const float* cur = e->d_canvas;
             int pp = 0;
             for (LayerDesc& L : e->layers) {

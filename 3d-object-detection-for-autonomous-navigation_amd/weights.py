@@ -42,6 +42,17 @@ def _he_uniform(rng, shape, fan_in):
     return rng.uniform(-lim, lim, size=shape).astype(np.float32)
 
 
+def _unit_gain_uniform(rng, shape, fan_in):
+    """Variance-preserving uniform init.  The reference initialises with he_uniform and
+    relies on TRAINED BatchNorm statistics to keep activations O(1); with random BN
+    statistics a gain of 2 per conv would grow the signal by ~4x per separable layer
+    (x 2^30 over the backbone), so the synthetic RPN kernels use gain 1 instead.  Head
+    outputs then have the O(1) magnitude of a trained detector, which is what the
+    1e-4 parity tolerance is meant for."""
+    lim = np.sqrt(3.0 / fan_in)
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
 def _bn(rng, c, prefix, out):
     out[prefix + "/gamma"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
     out[prefix + "/beta"] = rng.uniform(-0.5, 0.5, c).astype(np.float32)
@@ -57,15 +68,15 @@ def init_weights(d, seed=7):
     _bn(rng, d.pfn_filters, "pfn/bn", w)
     for kind, name, s in layer_table(d):
         if kind == "sep":
-            w[name + "/depthwise_kernel"] = _he_uniform(rng, (3, 3, s["cin"], 1), 9)
-            w[name + "/pointwise_kernel"] = _he_uniform(rng, (1, 1, s["cin"], s["cout"]), s["cin"])
+            w[name + "/depthwise_kernel"] = _unit_gain_uniform(rng, (3, 3, s["cin"], 1), 9)
+            w[name + "/pointwise_kernel"] = _unit_gain_uniform(rng, (1, 1, s["cin"], s["cout"]), s["cin"])
             _bn(rng, s["cout"], name + "/bn", w)
         elif kind == "deconv":
             k = s["k"]
-            w[name + "/kernel"] = _he_uniform(rng, (k, k, s["cout"], s["cin"]), s["cin"])
+            w[name + "/kernel"] = _unit_gain_uniform(rng, (k, k, s["cout"], s["cin"]), s["cin"])
             _bn(rng, s["cout"], name + "/bn", w)
         else:
-            w[name + "/kernel"] = _he_uniform(rng, (1, 1, s["cin"], s["cout"]), s["cin"])
+            w[name + "/kernel"] = _unit_gain_uniform(rng, (1, 1, s["cin"], s["cout"]), s["cin"])
             w[name + "/bias"] = rng.uniform(-0.1, 0.1, s["cout"]).astype(np.float32)
     return w
 

@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PointPillars inference frames/s on synthetic 16k-point d435i clouds.
+
+    python bench.py --gpus N --steps K --warmup W
+(for N > 1 the driver launches this under torch.distributed.run, one rank per GPU.)
+
+A "step" is one pass of the whole hot path (voxelise -> PFN + scatter -> anchor
+mask -> backbone + heads -> top-k / decode / NMS -> detections copied to pinned
+host memory) over one batch of B = 64 frames whose raw points are already
+resident in HBM when the timed region starts (BASELINE.json configs[1]; the
+shipped reference config, SURVEY "cfg-A").  Frames are independent, so with N
+GPUs every rank processes its own 64 frames (weak scaling, no collective on the
+data path); the timed region is bracketed by a barrier + device sync and the MAX
+over ranks is taken.
+
+The JSON line also carries
+  roofline      the dominant kernel (largest share of GPU time), its average
+                launch duration measured with HIP events on the engine's own
+                stream in this process, and algorithmic flops (or bytes) per
+                launch / that duration against the gfx950 peak;
+  cpu_baseline  the CPU oracle (a faithful restatement of the reference's
+                numpy/TF path: C voxeliser + numpy PFN + torch-CPU backbone +
+                numpy predict) timed on this host on a bounded sample, rank 0,
+                N == 1 only.  The literal TF-2.2 binary cannot run here
+                (DESIGN.md "CPU baseline").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+
+
+def layer_flops(d, batch):
+    """Algorithmic FLOPs per launch of every backbone layer:
+    depthwise 2*9*Cin + pointwise 2*Cin*Cout per output pixel; deconv 2*Cin*k*k*Cout per
+    input pixel; heads 2*384*(14+2+4) per pixel."""
+    out = {}
+    h, w, cin = d.ny, d.nx, d.pfn_filters
+    for b in range(3):
+        cout = d.num_filters[b]
+        for j in range(d.layer_nums[b] + 1):
+            s = d.layer_strides[b] if j == 0 else 1
+            h, w = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+            out[f"block{b + 1}.{j}"] = 2.0 * batch * h * w * (9 * cin + cin * cout)
+            cin = cout
+        k = d.upsample_strides[b]
+        out[f"deconv{b + 1}"] = 2.0 * batch * h * w * cin * k * k * d.num_upsample_filters[b]
+    n_head = d.num_anchor_per_loc * (7 + d.num_class + 2)
+    out["heads"] = 2.0 * batch * d.head_h * d.head_w * d.concat_channels * n_head
+    return out
+
+
+def stage_bytes(d, batch, n_points, n_pillars):
+    """Algorithmic HBM bytes per launch of the non-GEMM kernels."""
+    F, C = d.num_point_features, d.pfn_filters
+    return {
+        "k_cell_first": batch * (4 * F * n_points + 4 * n_points),
+        "k_voxel_frame": batch * (4 * n_points * 2 + 16 * n_pillars + 4 * n_points),
+        "k_pfn_canvas": batch * (4 * F * n_points + 16 * n_pillars + 4 * d.ny * d.nx * C),
+        "anchor_mask": batch * (4 * d.ny * d.nx * d.nz + 4 * d.ny * d.nx + d.num_anchors * 17),
+        "k_postprocess": batch * (d.num_anchors * 5),
+    }
+
+
+def cpu_baseline(pp, d, weights, frames, calib, budget_s=20.0):
+    """The oracle end to end on the host cores (checker code used as the CPU baseline)."""
+    import torch
+    import util_ref
+    rect, trv, p2 = calib
+    cores = torch.get_num_threads()
+    util_ref.oracle_detect(d, weights, frames[:1], rect, trv, p2, num_threads=cores)  # warm-up
+    done, t0 = 0, time.perf_counter()
+    lat = []
+    while done < len(frames) and time.perf_counter() - t0 < budget_s:
+        t1 = time.perf_counter()
+        util_ref.oracle_detect(d, weights, frames[done:done + 1], rect, trv, p2, num_threads=cores)
+        lat.append(time.perf_counter() - t1)
+        done += 1
+    el = time.perf_counter() - t0
+    return {"value": done / el, "unit": "frames/s", "cores": cores, "kind": "port",
+            "p50_ms_per_frame": float(np.median(lat) * 1e3),
+            "sample": f"{done} of the same synthetic 16k-point frames, batch 1 (the reference's eval batch), "
+                      f"C voxeliser + numpy PFN + torch-CPU fp32 backbone ({cores} threads) + numpy predict"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if world > 1 else 1
+
+    import pp_amd as pp
+    pp._lib.lib()  # fails loudly if the HIP library is missing
+    B, N = args.batch, args.points
+    cfg = pp.config.pedestrian_d435i_config(B)
+    eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=max(N, 4096), device=local_rank)
+    d = eng.d
+    weights = pp.weights.init_weights(d, seed=7)
+    eng.load_weights(weights)
+    calib = pp.synth.default_calib()
+    frames = [pp.synth.d435i_cloud(1000 * rank + i, N, d.num_point_features) for i in range(B)]
+    eng.upload(frames, np.stack([calib[0]] * B), np.stack([calib[1]] * B))   # points now resident in HBM
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.detect_async()
+    eng.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.detect_async()
+    eng.sync()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    fps = n_gpus * B * args.steps / elapsed
+    dets, n_det = eng.detections()
+    im_np = eng.intermediates()["n_pillars"]
+
+    # ---- per-kernel durations (HIP events on the engine's stream), same process ----
+    eng.set_profiling(True)
+    agg, per_layer = {}, {}
+    prof_steps = max(3, min(10, args.steps))
+    for _ in range(prof_steps):
+        eng.detect_async()
+        eng.sync()
+        for tag, ms in eng.kernel_times():
+            sym, _, layer = tag.partition(":")
+            a = agg.setdefault(sym, [0.0, 0])
+            a[0] += ms
+            a[1] += 1
+            if layer:
+                pl = per_layer.setdefault(tag, [0.0, 0])
+                pl[0] += ms
+                pl[1] += 1
+    eng.set_profiling(False)
+    kernel_ms = {k: v[0] / prof_steps for k, v in agg.items()}        # per step
+    launches = {k: v[1] / prof_steps for k, v in agg.items()}
+    dominant = max(kernel_ms, key=kernel_ms.get)
+    lf = layer_flops(d, B)
+    sb = stage_bytes(d, B, N, float(im_np.mean()))
+    if dominant.startswith("k_gemm_layer"):
+        flops_step = sum(lf[tag.split(":")[1]] for tag in per_layer if tag.startswith(dominant + ":"))
+        per_launch = flops_step / launches[dominant]
+        avg_ms = kernel_ms[dominant] / launches[dominant]
+        achieved = per_launch / (avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_ms": avg_ms, "launches_per_step": launches[dominant],
+                    "algorithmic_flops_per_launch": per_launch}
+    else:
+        key = dominant.split("(")[0]
+        per_launch = sb.get(key, 0.0) / max(launches[dominant], 1)
+        avg_ms = kernel_ms[dominant] / launches[dominant]
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "launches_per_step": launches[dominant], "algorithmic_bytes_per_launch": per_launch}
+    gpu_ms = sum(kernel_ms.values())
+    total_flops = sum(lf.values())
+    extras = {
+        "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
+        "layer_ms": {k: round(v[0] / v[1], 4) for k, v in per_layer.items()},
+        "sum_kernel_ms_per_step": gpu_ms,
+        "backbone_tflops_end_to_end": total_flops / (ms_per_step * 1e-3) / 1e12,
+    }
+
+    # ---- batch-1 latency (the reference's eval batch size): p50 per frame ----
+    lat = None
+    if rank == 0:
+        e1 = pp.Engine(pp.config.pedestrian_d435i_config(1), max_batch=1, max_points_per_frame=max(N, 4096),
+                       device=local_rank, weights=weights)
+        ts = []
+        for i in range(40):
+            e1.upload(frames[i % B:i % B + 1], calib[0][None], calib[1][None])
+            t1 = time.perf_counter()
+            e1.detect_async()
+            e1.sync()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        lat = float(np.median(ts[8:]))
+        e1.close()
+
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(pp, d, weights, frames[:32], calib)
+
+    if rank == 0:
+        info = eng.device_info()
+        line = {
+            "metric": "frames/sec (whole node) + p50 per-frame ms, 16k-pt pillars",
+            "value": fps, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg-A (shipped d435i pedestrian config, 80x64 BEV, T=50, C=128), "
+                                   f"B={B} frames/GPU x {N} pts, raw points -> detections end to end "
+                                   f"(BASELINE.json configs[1]); points resident in HBM",
+                       "batch_per_gpu": B, "points_per_frame": N, "parallelism": f"frame-parallel x{n_gpus}, no collective",
+                       "mean_pillars_per_frame": float(im_np.mean()), "mean_detections_per_frame": float(n_det.mean()),
+                       "device": info["name"], "compute_units": info["compute_units"]},
+            "p50_ms_per_frame_batch1": lat,
+            "ms_per_frame_in_batch": ms_per_step / B,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "detail": extras,
+        }
+        print(json.dumps(line))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,7 +39,7 @@ def oracle_detect(d, w, frames, rect, trv2c, p2, num_threads=None):
     return {"example": ex, "frames": fr, "preds": preds, "canvas": canvas, "features": feats, "dets": dets}
 
 
-def scale_heads(w, cls_scale=0.35, seed=11):
+def scale_heads(w, cls_scale=1.0, seed=11):
     """Spread the synthetic logits: keeps sigmoid scores off saturation so ties
     (whose order is implementation-defined in the reference) do not occur."""
     w = dict(w)
