@@ -126,7 +126,8 @@ def main():
     weights = pp.weights.init_weights(d, seed=7)
     eng.load_weights(weights)
     calib = pp.synth.default_calib()
-    frames = [pp.synth.d435i_cloud(1000 * rank + i, N, d.num_point_features) for i in range(B)]
+    frame_ids = pp.frame_shard.rank_frames(rank, n_gpus, B)     # this rank's frames (weak scaling)
+    frames = [pp.synth.d435i_cloud(i, N, d.num_point_features) for i in frame_ids]
     eng.upload(frames, np.stack([calib[0]] * B), np.stack([calib[1]] * B))   # points now resident in HBM
 
     def barrier():
@@ -145,12 +146,10 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pp.frame_shard.max_over_ranks(elapsed, dist, f"cuda:{local_rank}")
+    counts = pp.frame_shard.gather_counts(B * args.steps, dist, f"cuda:{local_rank}")
     ms_per_step = elapsed / args.steps * 1e3
-    fps = n_gpus * B * args.steps / elapsed
+    fps = sum(counts) / elapsed
     dets, n_det = eng.detections()
     im_np = eng.intermediates()["n_pillars"]
 

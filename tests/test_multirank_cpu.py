@@ -1,0 +1,66 @@
+"""World-size-2 gloo rehearsal of the N>1 path of bench.py (CPU; no GPU work).
+
+The data path has no collective: ranks own disjoint frames.  What crosses ranks
+is the barrier, the MAX of the elapsed time and the frame counts -- exercised
+here exactly as bench.py calls them.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import pp_amd as pp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = pp.frame_shard.rank_frames(rank, world, 4)
+    clouds = [pp.synth.d435i_cloud(i, 256) for i in ids]          # each rank builds only its own frames
+    dist.barrier()
+    elapsed = 1.0 + rank                                            # pretend rank 1 was slower
+    mx = pp.frame_shard.max_over_ranks(elapsed, dist)
+    counts = pp.frame_shard.gather_counts(len(clouds) * 3, dist)
+    dist.barrier()
+    q.put((rank, ids, float(clouds[0][0, 0]), mx, counts))
+    dist.destroy_process_group()
+
+
+def test_two_rank_frame_sharding_and_reduction():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ids0, x0, mx0, c0), (r1, ids1, x1, mx1, c1) = res
+    assert ids0 == [0, 1, 2, 3] and ids1 == [4, 5, 6, 7], "disjoint contiguous frame blocks"
+    assert x0 != x1, "ranks process different frames"
+    assert mx0 == mx1 == 2.0, "MAX over ranks of the elapsed time"
+    assert c0 == c1 == [12, 12]
+    fps = sum(c0) / mx0
+    assert fps == 12.0, "whole-job throughput = all frames / slowest rank"
+
+
+def test_split_frames_strong_scaling(pp):
+    assert pp.frame_shard.split_frames(512, 8) == [(i * 64, (i + 1) * 64) for i in range(8)]
+    s = pp.frame_shard.split_frames(10, 4)
+    assert s == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    with pytest.raises(ValueError):
+        pp.frame_shard.rank_frames(3, 2, 4)
