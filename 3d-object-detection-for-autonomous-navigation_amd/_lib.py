@@ -23,7 +23,7 @@ EXPORTS = [
     "pp_set_anchors", "pp_points_to_voxel", "pp_anchor_mask", "pp_forward_voxels", "pp_predict",
     "pp_upload_points", "pp_upload_points_device", "pp_set_calib", "pp_detect_async", "pp_sync",
     "pp_get_detections", "pp_detect", "pp_fetch_intermediates", "pp_set_profiling", "pp_get_kernel_times",
-    "pp_timer_start", "pp_timer_stop", "pp_device_info",
+    "pp_timer_start", "pp_timer_stop", "pp_device_info", "pp_bench_layer", "pp_layer_count", "pp_layer_tag",
 ]
 
 
@@ -130,9 +130,13 @@ def lib():
     L.pp_timer_start.argtypes = [vp]
     L.pp_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.pp_device_info.argtypes = [vp, ctypes.c_char_p, i32, ctypes.POINTER(i32), ctypes.POINTER(i64)]
+    L.pp_bench_layer.argtypes = [vp, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_float)]
+    L.pp_layer_count.argtypes = [vp, ctypes.POINTER(i32)]
+    L.pp_layer_tag.argtypes = [vp, i32]
+    L.pp_layer_tag.restype = ctypes.c_char_p
     for name in EXPORTS:
         fn = getattr(L, name)  # raises AttributeError if the symbol is not exported
-        if name not in ("pp_last_error",):
+        if name not in ("pp_last_error", "pp_layer_tag"):
             fn.restype = ctypes.c_int
     _lib = L
     return L

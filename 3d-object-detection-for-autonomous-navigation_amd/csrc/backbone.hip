@@ -41,7 +41,9 @@ struct GemmArgs {
     float* box;
     float* cls;
     float* dir;
-    long long M;          // GEMM rows (pixels)
+    int M;                // GEMM rows (pixels) < 2^31 (checked by the launcher)
+    int dbg;              // tuning aid: ablation bits (pp_bench_layer), 0 in production
+    long long* stamps;    // tuning aid (dbg & 64): [block<64][role 2][iter 40][4] shader-clock stamps
     int in_h, in_w, cin;
     int px_h, px_w;       // pixel space of M (sep: output map; deconv/head: input map)
     int stride;
@@ -51,10 +53,64 @@ struct GemmArgs {
     int nb, nc, nd;       // head widths
 };
 
+// D[row][col] of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// s_opix (LDS, deconv only): output pixel index of tap (0,0) for each of the tile's 128 input pixels.
+template <int NTILES>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NTILES], int p0, int n0, int wave,
+                                              int lane, const int* s_opix) {
+    const int h = lane >> 5, col_l = lane & 31;
+    if (a.dbg & 4) return;
+    if (a.epi == 0) {
+#pragma unroll
+        for (int n = 0; n < NTILES; ++n) {
+            const int col = n0 + n * 32 + col_l;
+            const float bv = a.bias[col];
+            float* dst = a.out + a.co_off + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (pix < a.M) dst[(size_t)pix * a.ld_out] = fmaxf(acc[n][r] + bv, 0.f);
+            }
+        }
+    } else if (a.epi == 1) {
+        // Conv2DTranspose, kernel == stride: out[y*k+i][x*k+j][co] = sum_ci in[y][x][ci] * K[i][j][co][ci].
+        // All integer divisions here are wave-uniform (one tap per 32-column tile).
+        const int k = a.k, OW = a.px_w * k;
+#pragma unroll
+        for (int n = 0; n < NTILES; ++n) {
+            const int col0 = __builtin_amdgcn_readfirstlane(n0 + n * 32);
+            const int tap = col0 / a.cout, co = col0 - tap * a.cout + col_l;
+            const int i = tap / k, j = tap - i * k;
+            const int delta = i * OW + j;
+            const float bv = a.bias[co];
+            float* dst = a.out + a.co_off + co;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (p0 + row < a.M) dst[(size_t)(s_opix[row] + delta) * a.ld_out] = fmaxf(acc[n][r] + bv, 0.f);
+            }
+        }
+    } else {
+        // heads: columns [0,nb) box, [nb,nb+nc) cls, [nb+nc,nb+nc+nd) dir; bias, no activation
+        const int col = n0 + col_l;
+        const float bv = a.bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pix = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (pix >= a.M) continue;
+            const float v = acc[0][r] + bv;
+            if (col < a.nb) a.box[(size_t)pix * a.nb + col] = v;
+            else if (col < a.nb + a.nc) a.cls[(size_t)pix * a.nc + (col - a.nb)] = v;
+            else if (col < a.nb + a.nc + a.nd) a.dir[(size_t)pix * a.nd + (col - a.nb - a.nc)] = v;
+        }
+    }
+}
+
 template <int NT, int MODE>
 __global__ __launch_bounds__(256) void k_gemm_layer(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float sA[PX_TILE * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float sB[NT * LDS_STRIDE];
+    __shared__ int s_opix[PX_TILE];
     constexpr int NTILES = NT / 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,9 +121,16 @@ __global__ __launch_bounds__(256) void k_gemm_layer(GemmArgs a) {
         const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
         mt = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const long long p0 = (long long)mt * PX_TILE;
+    const int p0 = mt * PX_TILE;
     const int n0 = blockIdx.y * NT;
     const int cin = a.cin;
+    if (a.epi == 1 && tid < PX_TILE) {   // deconv: output pixel of tap (0,0) per input pixel (read after the K loop's barriers)
+        const int pix = min(p0 + tid, a.M - 1);
+        const int hw = a.px_h * a.px_w;
+        const int b = pix / hw, rem = pix - b * hw;
+        const int y = rem / a.px_w, x = rem - y * a.px_w;
+        s_opix[tid] = (b * a.px_h * a.k + y * a.k) * (a.px_w * a.k) + x * a.k;
+    }
 
     // this thread's 4 staging items: pixel (tid>>3) + 32*it, channel group tid&7
     const int c4 = tid & 7;
@@ -75,14 +138,14 @@ __global__ __launch_bounds__(256) void k_gemm_layer(GemmArgs a) {
     int yi0[4], xi0[4];
     bool pvalid[4];
     {
-        const long long hw = (long long)a.px_h * a.px_w;
+        const int hw = a.px_h * a.px_w;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const long long pix = p0 + (tid >> 3) + 32 * it;
+            const int pix = p0 + (tid >> 3) + 32 * it;
             pvalid[it] = pix < a.M;
-            const long long pc = pvalid[it] ? pix : 0;
-            const int b = (int)(pc / hw);
-            const int rem = (int)(pc - (long long)b * hw);
+            const int pc = pvalid[it] ? pix : 0;
+            const int b = pc / hw;
+            const int rem = pc - b * hw;
             const int yo = rem / a.px_w, xo = rem - yo * a.px_w;
             if (MODE == 0) {
                 yi0[it] = yo * a.stride - 1;
@@ -168,53 +231,298 @@ __global__ __launch_bounds__(256) void k_gemm_layer(GemmArgs a) {
         }
     }
 
-    // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
-    const int h = lane >> 5, col_l = lane & 31;
-    if (a.epi == 0) {
-#pragma unroll
-        for (int n = 0; n < NTILES; ++n) {
-            const int col = n0 + n * 32 + col_l;
-            const float bv = a.bias[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long pix = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (pix < a.M) a.out[(size_t)pix * a.ld_out + a.co_off + col] = fmaxf(acc[n][r] + bv, 0.f);
-            }
-        }
-    } else if (a.epi == 1) {
-        // Conv2DTranspose, kernel == stride: out[y*k+i][x*k+j][co] = sum_ci in[y][x][ci] * K[i][j][co][ci]
-        const int k = a.k, OW = a.px_w * k;
-        const long long hw = (long long)a.px_h * a.px_w;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long pix = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (pix >= a.M) continue;
-            const int b = (int)(pix / hw);
-            const int rem = (int)(pix - (long long)b * hw);
+    gemm_epilogue<NTILES>(a, acc, p0, n0, wave, lane, s_opix);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Wave-specialised, software-pipelined variant (the fast path).
+//
+// 8 wavefronts per workgroup: waves 0-3 are CONSUMERS (one 32-pixel MFMA row block each,
+// accumulators + fragments only), waves 4-7 are PRODUCERS (global loads, the depthwise 3x3
+// on the VALU, LDS stores).  A workgroup's waves w and w+4 share a SIMD, so every SIMD hosts
+// one MFMA wave and one VALU wave: the matrix pipe and the vector pipe run concurrently
+// instead of taking turns inside one instruction stream.  LDS tiles are double-buffered:
+// while the consumers run the MFMAs of K-chunk k out of buffer k&1, the producers turn the
+// (already prefetched) registers of chunk k+1 into buffer (k+1)&1 and issue the global loads
+// of chunk k+2; one workgroup barrier per K-chunk.  Register budgets of both roles are kept
+// under 128 VGPRs so that two workgroups fit a CU and one's prologue / epilogue overlaps the
+// other's MFMA phase.
+//   MODE 0  separable layer (stride S = 1 or 2, output width even): K-chunks of 16
+//           channels; a producer thread owns 2 consecutive output pixels of one row x 4
+//           channels and slides a 3 x (S+3) input window (bounds tests once per row / column).
+//   MODE 1  plain GEMM (Conv2DTranspose, heads): K-chunks of 32, producers copy A rows.
+// The epilogue stages each consumer wave's 32 x NT tile through LDS and writes whole
+// channel rows with 16-byte stores (full 128-B lines).  Odd-width separable layers use
+// k_gemm_layer above.
+template <int NT, int MODE, int S>
+__global__ __launch_bounds__(512, 4) void k_gemm_ws(GemmArgs a) {
+    constexpr int KCH = (MODE == 0) ? 16 : 32;      // channels per K-chunk
+    constexpr int LSTR = KCH + 4;                    // LDS row stride (floats): conflict-free ds_read_b128
+    constexpr int G = KCH / 4;                       // float4 channel groups per row
+    constexpr int PXT = PX_TILE * G / 256;           // pixels per producer thread (2 or 4)
+    constexpr int WW = (MODE == 0) ? (PXT - 1) * S + 3 : 1;   // input window width
+    constexpr int NLD = (MODE == 0) ? 3 * WW : PXT;  // activation float4 loads per thread per chunk
+    constexpr int SA = PX_TILE * LSTR, SB = NT * LSTR;
+    constexpr int NB4 = (NT * G + 255) / 256;        // weight float4 per producer thread per chunk
+    constexpr int NTILES = NT / 32;
+    constexpr int KQ = KCH / 8;                      // float4 fragment reads per operand per chunk
+    // one LDS arena: [sA buf0 | sA buf1 | sB buf0 | sB buf1]; the epilogue re-uses it as the
+    // consumers' output staging area
+    constexpr int DWMAX = (MODE == 0) ? 9 * 256 : 0;   // depthwise taps [9][cin], cin <= 256 on this path
+    constexpr int ARENA = (2 * SA + 2 * SB + DWMAX > 4 * 32 * NT) ? (2 * SA + 2 * SB + DWMAX) : (4 * 32 * NT);
+    __shared__ __attribute__((aligned(16))) float smem[ARENA];
+    __shared__ int s_opix[PX_TILE];
+    float* const sA = smem;
+    float* const sB = smem + 2 * SA;
+    float* const sDW = smem + 2 * SA + 2 * SB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int mt;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        mt = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int p0 = mt * PX_TILE;
+    const int n0 = blockIdx.y * NT;
+    const int cin = a.cin;
+    const int nchunks = cin / KCH;
+    const int dbg = a.dbg;
+
+    if (tid < PX_TILE) {   // output pixel index per tile row (deconv: pixel of tap (0,0))
+        const int pix = min(p0 + tid, a.M - 1);
+        int o = pix;
+        if (a.epi == 1) {
+            const int hw = a.px_h * a.px_w;
+            const int b = pix / hw, rem = pix - b * hw;
             const int y = rem / a.px_w, x = rem - y * a.px_w;
+            o = (b * a.px_h * a.k + y * a.k) * (a.px_w * a.k) + x * a.k;
+        }
+        s_opix[tid] = o;
+    }
+
+    if (MODE == 0) {   // depthwise taps of the whole layer -> LDS once (visible after the first barrier)
+        for (int e = tid; e < 9 * cin / 4; e += 512)
+            reinterpret_cast<float4*>(sDW)[e] = reinterpret_cast<const float4*>(a.dw)[e];
+    }
+
+    if (wave >= 4) {
+        // =============================== producers ===============================
+        const int pt = tid - 256;
+        const int c4 = pt % G, q = pt / G;            // channel group, pixel group
+        const int pix0 = p0 + PXT * q;                // first of this thread's pixels (M % PXT == 0)
+        const bool pvalid = pix0 < a.M;
+        const int pc = pvalid ? pix0 : 0;
+        // addressing: uniform base pointer + 32-bit BYTE offsets (saddr + voffset loads: one VGPR per
+        // address).  cbase = this thread's first pixel (MODE 0: the centre (dy=1,dx=1) of its window),
+        // always inside the map; an out-of-map window element reads the centre instead and is zeroed
+        // when it is consumed (a select on the LOADED value would serialise the loads).
+        const char* const inb = reinterpret_cast<const char*>(a.in);
+        const char* const wtb = reinterpret_cast<const char*>(a.wt);
+        unsigned cbase;
+        unsigned okmask = 0;                          // bit dy*WW+dx: that window element is inside the map
+        if (MODE == 0) {
+            const int hw = a.px_h * a.px_w;
+            const int b = pc / hw;
+            const int rem = pc - b * hw;
+            const int y = rem / a.px_w, x0 = rem - y * a.px_w;
+            const int yi = y * S - 1, xi = x0 * S - 1;
+            cbase = (unsigned)(((b * a.in_h + y * S) * a.in_w + x0 * S) * cin) * 4u;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < WW; ++dx)
+                    if (pvalid && yi + dy >= 0 && yi + dy < a.in_h && xi + dx >= 0 && xi + dx < a.in_w && !(dbg & 8))
+                        okmask |= 1u << (dy * WW + dx);
+        } else {
+            cbase = (unsigned)(pc * cin) * 4u;
+            if (pvalid && !(dbg & 8)) okmask = 1u;
+        }
+        const int rs4 = a.in_w * cin * 4, cin4 = cin * 4;   // row / pixel stride in bytes (uniform)
+        float4 rin[NLD];
+        float4 rb0, rb1, rb2, rb3;   // weight prefetch (named scalars: an array here ended up in scratch)
+        rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        static_assert(NB4 <= 4, "weight prefetch registers");
+        float* const dA = sA + (PXT * q) * LSTR + c4 * 4;
+
+        // (a macro, not a lambda: by-reference captures of rin / rb kept those arrays in scratch memory)
+#define WS_LOAD_CHUNK(KCIDX)                                                                             \
+        {                                                                                                \
+            const unsigned chb_ = (unsigned)((KCIDX) * KCH + c4 * 4) * 4u;                               \
+            _Pragma("unroll") for (int e = 0; e < NLD; ++e) {                                            \
+                int rel_;                                                                                \
+                if (MODE == 0) rel_ = ((okmask >> e) & 1u) ? ((e / WW - 1) * rs4 + (e % WW - 1) * cin4) : 0; \
+                else rel_ = e * cin4;                                                                    \
+                rin[e] = *reinterpret_cast<const float4*>(inb + (cbase + chb_ + (unsigned)rel_));        \
+            }                                                                                            \
+            WS_LOAD_B(0, rb0, KCIDX) WS_LOAD_B(1, rb1, KCIDX) WS_LOAD_B(2, rb2, KCIDX) WS_LOAD_B(3, rb3, KCIDX) \
+        }
+#define WS_LOAD_B(R, REG, KCIDX)                                                                         \
+        if (NB4 > (R)) {                                                                                 \
+            const int e_ = pt + 256 * (R);                                                               \
+            if ((NT * G) % 256 == 0 || e_ < NT * G)                                                      \
+                REG = *reinterpret_cast<const float4*>(                                                  \
+                    wtb + (unsigned)(((n0 + e_ / G) * cin + (KCIDX) * KCH + (e_ % G) * 4) * 4));         \
+        }
+#define WS_STORE_B(R, REG)                                                                               \
+        if (NB4 > (R)) {                                                                                 \
+            const int e_ = pt + 256 * (R);                                                               \
+            if ((NT * G) % 256 == 0 || e_ < NT * G)                                                      \
+                *reinterpret_cast<float4*>(sB + buf * SB + (e_ / G) * LSTR + (e_ % G) * 4) = REG;        \
+        }
+        // s = -1 is the pipeline prologue (nothing staged yet)
+        {
+            // loads of chunk 0 (always issued, from a clamped address when the element is outside the
+            // map: a select on the LOADED value would make the compiler wait for each load in turn)
+            WS_LOAD_CHUNK(0)
+        }
+        __syncthreads();   // (A) depthwise taps / s_opix visible; chunk-0 loads are already in flight
+        const bool stamp = (dbg & 64) && a.stamps != nullptr && blockIdx.x < 64 && blockIdx.y == 0 && pt == 0;
+        long long* st = a.stamps ? a.stamps + ((size_t)blockIdx.x * 2 + 1) * 40 * 4 : nullptr;
+        for (int s = -1; s < nchunks; ++s) {
+            if (stamp && s + 1 < 40) st[(s + 1) * 4 + 0] = clock64();
+            if (s + 1 < nchunks) {
+                // ---- stage chunk s+1 (registers -> LDS buffer (s+1)&1) ----
+                const int kc = s + 1, buf = kc & 1;
+                float* dst = dA + buf * SA;
+                if (MODE == 0) {
+                    const int ch = kc * KCH + c4 * 4;
+                    float4 o[PXT];
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j) o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int e = 0; e < NLD; ++e)
+                        if (!((okmask >> e) & 1u)) { rin[e].x = 0.f; rin[e].y = 0.f; rin[e].z = 0.f; rin[e].w = 0.f; }
+                    if (!(dbg & 2)) {
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const float4 wv = *reinterpret_cast<const float4*>(sDW + (dy * 3 + dx) * cin + ch);
+#pragma unroll
+                                for (int j = 0; j < PXT; ++j) {
+                                    const float4 v = rin[dy * WW + j * S + dx];
+                                    o[j].x = fmaf(v.x, wv.x, o[j].x);
+                                    o[j].y = fmaf(v.y, wv.y, o[j].y);
+                                    o[j].z = fmaf(v.z, wv.z, o[j].z);
+                                    o[j].w = fmaf(v.w, wv.w, o[j].w);
+                                }
+                            }
+                    }
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j) *reinterpret_cast<float4*>(dst + j * LSTR) = o[j];
+                } else {
+                    const float km = okmask ? 1.f : 0.f;   // (a ?: between two float4 lvalues would force rin into memory)
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j) {
+                        float4 t = rin[j];
+                        if (!okmask) { t.x = 0.f; t.y = 0.f; t.z = 0.f; t.w = 0.f; }
+                        (void)km;
+                        *reinterpret_cast<float4*>(dst + j * LSTR) = t;
+                    }
+                }
+                WS_STORE_B(0, rb0) WS_STORE_B(1, rb1) WS_STORE_B(2, rb2) WS_STORE_B(3, rb3)
+                if (stamp && s + 1 < 40) st[(s + 1) * 4 + 1] = clock64();
+                // ---- issue the loads of chunk s+2 ----
+                if (s + 2 < nchunks) WS_LOAD_CHUNK(s + 2)
+            }
+            if (stamp && s + 1 < 40) st[(s + 1) * 4 + 2] = clock64();
+            __syncthreads();
+            if (stamp && s + 1 < 40) st[(s + 1) * 4 + 3] = clock64();
+        }
+        return;
+#undef WS_LOAD_CHUNK
+#undef WS_LOAD_B
+#undef WS_STORE_B
+    }
+
+    // =============================== consumers ===============================
+    f32x16 acc[NTILES];
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const int h = lane >> 5, r32 = lane & 31;
+    __syncthreads();   // (A)
+    const bool stamp = (dbg & 64) && a.stamps != nullptr && blockIdx.x < 64 && blockIdx.y == 0 && tid == 0;
+    long long* st = a.stamps ? a.stamps + ((size_t)blockIdx.x * 2 + 0) * 40 * 4 : nullptr;
+    if (stamp) st[0] = clock64();
+    __syncthreads();   // chunk 0 staged
+    if (stamp) st[3] = clock64();
+    for (int k = 0; k < nchunks; ++k) {
+        if (stamp && k + 1 < 40) st[(k + 1) * 4 + 0] = clock64();
+        const float* cA = sA + (k & 1) * SA + (wave * 32 + r32) * LSTR + h * (KCH / 2);
+        const float* cB = sB + (k & 1) * SB + r32 * LSTR + h * (KCH / 2);
+        float4 a4[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) a4[q] = *reinterpret_cast<const float4*>(cA + q * 4);
+        if (!(dbg & 1)) {
 #pragma unroll
             for (int n = 0; n < NTILES; ++n) {
-                const int col = n0 + n * 32 + col_l;
-                const int tap = col / a.cout, co = col - tap * a.cout;
-                const int i = tap / k, j = tap - i * k;
-                const size_t opix = ((size_t)b * a.px_h * k + (size_t)y * k + i) * OW + (size_t)x * k + j;
-                a.out[opix * a.ld_out + a.co_off + co] = fmaxf(acc[n][r] + a.bias[co], 0.f);
+                float4 b4[KQ];
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) b4[q] = *reinterpret_cast<const float4*>(cB + n * 32 * LSTR + q * 4);
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].x, b4[q].x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].y, b4[q].y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].z, b4[q].z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].w, b4[q].w, acc[n], 0, 0, 0);
+                }
             }
         }
-    } else {
-        // heads: columns [0,nb) box, [nb,nb+nc) cls, [nb+nc,nb+nc+nd) dir; bias, no activation
-        const int col = n0 + col_l;
-        const float bv = a.bias[col];
+        if (stamp && k + 1 < 40) { asm volatile("" :: "v"(acc[0][0])); st[(k + 1) * 4 + 2] = clock64(); }
+        __syncthreads();
+        if (stamp && k + 1 < 40) st[(k + 1) * 4 + 3] = clock64();
+    }
+    if (a.epi == 2) {
+        gemm_epilogue<NTILES>(a, acc, p0, n0, wave, lane, s_opix);
+        return;
+    }
+    // ---- coalesced epilogue: accumulators -> this wave's LDS rows -> 16-byte stores of whole
+    // channel rows (the final barrier of the K loop guarantees nobody still reads the arena) ----
+    if (dbg & 4) return;
+    float* so = smem + wave * 32 * NT;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long pix = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (pix >= a.M) continue;
-            const float v = acc[0][r] + bv;
-            if (col < a.nb) a.box[(size_t)pix * a.nb + col] = v;
-            else if (col < a.nb + a.nc) a.cls[(size_t)pix * a.nc + (col - a.nb)] = v;
-            else if (col < a.nb + a.nc + a.nd) a.dir[(size_t)pix * a.nd + (col - a.nb - a.nc)] = v;
+    for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) so[((r & 3) + 8 * (r >> 2) + 4 * h) * NT + n * 32 + r32] = acc[n][r];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int ROW4 = NT / 4;                 // float4 per staged row
+    const int c4 = lane % ROW4;                  // constant per lane: 64 % ROW4 == 0
+    int cbase = n0, delta = 0;
+    if (a.epi == 1) {
+        const int tap = n0 / a.cout, i = tap / a.k;
+        cbase = n0 - tap * a.cout;
+        delta = i * (a.px_w * a.k) + (tap - i * a.k);
+    }
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + cbase + c4 * 4);
+    float* dst = a.out + a.co_off + cbase + c4 * 4;
+    // batches of 4 rows-per-lane: all LDS reads first, then the stores (no per-store wait)
+#pragma unroll
+    for (int it0 = 0; it0 < NT / 8; it0 += 4) {
+        float4 v[4];
+        int op[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = ((it0 + u) * 64 + lane) / ROW4;
+            v[u] = *reinterpret_cast<const float4*>(so + row * NT + c4 * 4);
+            op[u] = s_opix[wave * 32 + row];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = ((it0 + u) * 64 + lane) / ROW4;
+            float4 w = v[u];
+            w.x = fmaxf(w.x + bv.x, 0.f); w.y = fmaxf(w.y + bv.y, 0.f);
+            w.z = fmaxf(w.z + bv.z, 0.f); w.w = fmaxf(w.w + bv.w, 0.f);
+            if (p0 + wave * 32 + row < a.M)
+                *reinterpret_cast<float4*>(dst + (size_t)(op[u] + delta) * a.ld_out) = w;
         }
     }
+    if (stamp) st[39 * 4 + 1] = clock64();
 }
 
 template <int NT, int MODE>
@@ -224,17 +532,48 @@ static void launch_t(const GemmArgs& a, int n_total, hipStream_t s) {
     hipLaunchKernelGGL((k_gemm_layer<NT, MODE>), grid, dim3(256), 0, s, a);
 }
 
+template <int NT, int MODE, int S>
+static void launch_ws(const GemmArgs& a, int n_total, hipStream_t s) {
+    const unsigned mt = (unsigned)((a.M + PX_TILE - 1) / PX_TILE);
+    dim3 grid(mt, n_total / NT);
+    hipLaunchKernelGGL((k_gemm_ws<NT, MODE, S>), grid, dim3(512), 0, s, a);
+}
+
+long long* g_stamps = nullptr;   // tuning aid: device buffer for in-kernel stamps (pp_bench_layer, ablate & 64)
+
+// which kernel runs layer L (shared by the launcher and the profiler tags)
+static bool use_ws(const LayerDesc& L) {
+    // MODE 1 producers own 4 consecutive pixels, MODE 0 producers 2 of one row: the frame's pixel
+    // count (hence every batch's) must be divisible accordingly, else the generic kernel runs
+    if (L.kind != LAYER_SEP) return (L.in_h * L.in_w) % 4 == 0;
+    return (L.stride == 1 || L.stride == 2) && (L.out_w % 2 == 0);
+}
+
 const char* layer_kernel_name(const LayerDesc& L) {
     const int nt = (L.kind == LAYER_HEAD) ? 32 : (L.cout % 128 == 0 ? 128 : (L.cout % 64 == 0 ? 64 : 32));
+    if (use_ws(L)) {
+        if (L.kind == LAYER_SEP) {
+            if (L.stride == 1) return nt == 128 ? "k_gemm_ws<128,0,1>" : (nt == 64 ? "k_gemm_ws<64,0,1>" : "k_gemm_ws<32,0,1>");
+            return nt == 128 ? "k_gemm_ws<128,0,2>" : (nt == 64 ? "k_gemm_ws<64,0,2>" : "k_gemm_ws<32,0,2>");
+        }
+        return nt == 128 ? "k_gemm_ws<128,1,1>" : (nt == 64 ? "k_gemm_ws<64,1,1>" : "k_gemm_ws<32,1,1>");
+    }
     if (L.kind == LAYER_SEP) return nt == 128 ? "k_gemm_layer<128,0>" : (nt == 64 ? "k_gemm_layer<64,0>" : "k_gemm_layer<32,0>");
     return nt == 128 ? "k_gemm_layer<128,1>" : (nt == 64 ? "k_gemm_layer<64,1>" : "k_gemm_layer<32,1>");
 }
 
 int launch_layer(const LayerDesc& L, int batch, float* d_box, float* d_cls, float* d_dir, int napl,
-                 hipStream_t s) {
+                 hipStream_t s, int ablate) {
     if (batch <= 0) return 0;
     if (L.cin % KC != 0) return PP_ERR_UNSUPPORTED;
+    {
+        const long long m_sep = (long long)batch * L.out_h * L.out_w, m_in = (long long)batch * L.in_h * L.in_w;
+        if (m_sep >= (1ll << 31) - PX_TILE || m_in >= (1ll << 31) - PX_TILE ||
+            (long long)batch * L.out_h * L.out_w * L.k * L.k >= (1ll << 31)) return PP_ERR_UNSUPPORTED;
+    }
     GemmArgs a;
+    a.dbg = ablate;
+    a.stamps = g_stamps;
     a.in = L.in; a.dw = L.d_dw; a.wt = L.d_wt; a.bias = L.d_bias; a.out = L.out;
     a.box = d_box; a.cls = d_cls; a.dir = d_dir;
     a.in_h = L.in_h; a.in_w = L.in_w; a.cin = L.cin;
@@ -243,23 +582,42 @@ int launch_layer(const LayerDesc& L, int batch, float* d_box, float* d_cls, floa
     a.nb = napl * 7; a.nc = napl; a.nd = napl * 2;
     if (L.kind == LAYER_SEP) {
         a.px_h = L.out_h; a.px_w = L.out_w; a.epi = 0;
-        a.M = (long long)batch * L.out_h * L.out_w;
-        if (L.cout % 128 == 0) launch_t<128, 0>(a, L.n_total, s);
-        else if (L.cout % 64 == 0) launch_t<64, 0>(a, L.n_total, s);
-        else if (L.cout % 32 == 0) launch_t<32, 0>(a, L.n_total, s);
-        else return PP_ERR_UNSUPPORTED;
+        a.M = batch * L.out_h * L.out_w;
+        if (L.cout % 32 != 0) return PP_ERR_UNSUPPORTED;
+        if (use_ws(L)) {
+            if (L.stride == 1) {
+                if (L.cout % 128 == 0) launch_ws<128, 0, 1>(a, L.n_total, s);
+                else if (L.cout % 64 == 0) launch_ws<64, 0, 1>(a, L.n_total, s);
+                else launch_ws<32, 0, 1>(a, L.n_total, s);
+            } else {
+                if (L.cout % 128 == 0) launch_ws<128, 0, 2>(a, L.n_total, s);
+                else if (L.cout % 64 == 0) launch_ws<64, 0, 2>(a, L.n_total, s);
+                else launch_ws<32, 0, 2>(a, L.n_total, s);
+            }
+        } else {
+            if (L.cout % 128 == 0) launch_t<128, 0>(a, L.n_total, s);
+            else if (L.cout % 64 == 0) launch_t<64, 0>(a, L.n_total, s);
+            else launch_t<32, 0>(a, L.n_total, s);
+        }
     } else if (L.kind == LAYER_DECONV) {
         a.px_h = L.in_h; a.px_w = L.in_w; a.epi = 1;
-        a.M = (long long)batch * L.in_h * L.in_w;
-        if (L.cout % 128 == 0) launch_t<128, 1>(a, L.n_total, s);
-        else if (L.cout % 64 == 0) launch_t<64, 1>(a, L.n_total, s);
-        else if (L.cout % 32 == 0) launch_t<32, 1>(a, L.n_total, s);
-        else return PP_ERR_UNSUPPORTED;
+        a.M = batch * L.in_h * L.in_w;
+        if (L.cout % 32 != 0) return PP_ERR_UNSUPPORTED;
+        if (use_ws(L)) {
+            if (L.cout % 128 == 0) launch_ws<128, 1, 1>(a, L.n_total, s);
+            else if (L.cout % 64 == 0) launch_ws<64, 1, 1>(a, L.n_total, s);
+            else launch_ws<32, 1, 1>(a, L.n_total, s);
+        } else {
+            if (L.cout % 128 == 0) launch_t<128, 1>(a, L.n_total, s);
+            else if (L.cout % 64 == 0) launch_t<64, 1>(a, L.n_total, s);
+            else launch_t<32, 1>(a, L.n_total, s);
+        }
     } else {
         a.px_h = L.in_h; a.px_w = L.in_w; a.epi = 2;
-        a.M = (long long)batch * L.in_h * L.in_w;
+        a.M = batch * L.in_h * L.in_w;
         if (L.n_total != 32) return PP_ERR_UNSUPPORTED;
-        launch_t<32, 1>(a, L.n_total, s);
+        if (use_ws(L)) launch_ws<32, 1, 1>(a, L.n_total, s);
+        else launch_t<32, 1>(a, L.n_total, s);
     }
     return 0;
 }

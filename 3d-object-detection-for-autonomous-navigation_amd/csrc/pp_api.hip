@@ -854,6 +854,62 @@ int pp_timer_stop(pp_handle e, float* elapsed_ms) {
     return PP_OK;
 }
 
+int pp_layer_count(pp_handle e, int32_t* count) {
+    if (!e || !count) return PP_ERR_ARG;
+    *count = (int32_t)e->layers.size();
+    return PP_OK;
+}
+
+const char* pp_layer_tag(pp_handle e, int32_t layer) {
+    if (!e || layer < 0 || layer >= (int)e->layer_tags.size()) return "";
+    return e->layer_tags[layer].c_str();
+}
+
+extern long long* g_stamps;
+
+int pp_bench_layer(pp_handle e, int32_t layer, int32_t batch, int32_t reps, int32_t ablate, float* avg_ms) {
+    if (!e) return PP_ERR_ARG;
+    if (!avg_ms || reps < 1 || layer < 0 || layer >= (int)e->layers.size()) return fail(e, PP_ERR_ARG, "pp_bench_layer: bad argument");
+    if (!e->weights_ready) return fail(e, PP_ERR_STATE, "pp_bench_layer: weights not finalised");
+    (void)hipSetDevice(e->device);
+    int st = check_batch(e, batch); if (st) return st;
+    const LayerDesc& L = e->layers[layer];
+    if ((ablate & 64) && !g_stamps) HIPCHK(e, hipMalloc((void**)&g_stamps, 64 * 2 * 40 * 4 * sizeof(long long)));
+    for (int i = 0; i < 2; ++i)
+        if ((st = launch_layer(L, batch, e->d_box, e->d_cls, e->d_dir, e->napl, e->stream, ablate))) return fail(e, st, "pp_bench_layer: unsupported layer");
+    HIPCHK(e, hipEventRecord(e->t0, e->stream));
+    for (int i = 0; i < reps; ++i) launch_layer(L, batch, e->d_box, e->d_cls, e->d_dir, e->napl, e->stream, ablate);
+    HIPCHK(e, hipEventRecord(e->t1, e->stream));
+    HIPCHK(e, hipEventSynchronize(e->t1));
+    HIPCHK(e, hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->t0, e->t1));
+    *avg_ms = ms / reps;
+    if (ablate & 64) {   // in-kernel stamps of one extra launch -> stderr (tuning aid)
+        const size_t n = 64 * 2 * 40 * 4;
+        std::vector<long long> hs(n, 0);
+        HIPCHK(e, hipMemsetAsync(g_stamps, 0, n * sizeof(long long), e->stream));
+        launch_layer(L, batch, e->d_box, e->d_cls, e->d_dir, e->napl, e->stream, ablate);
+        HIPCHK(e, hipMemcpyAsync(hs.data(), g_stamps, n * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        for (int blk : {0, 1, 8, 63}) {
+            for (int role = 0; role < 2; ++role) {
+                const long long* st = hs.data() + ((size_t)blk * 2 + role) * 160;
+                const long long t0 = hs[((size_t)blk * 2 + 0) * 160];
+                fprintf(stderr, "blk %2d %s:", blk, role ? "prod" : "cons");
+                for (int i = 0; i < 20; ++i) {
+                    if (!st[i * 4 + 3] && !st[i * 4]) continue;
+                    fprintf(stderr, " [%d: %lld %lld %lld %lld]", i, st[i * 4] ? st[i * 4] - t0 : -1, st[i * 4 + 1] ? st[i * 4 + 1] - t0 : -1,
+                            st[i * 4 + 2] ? st[i * 4 + 2] - t0 : -1, st[i * 4 + 3] ? st[i * 4 + 3] - t0 : -1);
+                }
+                if (!role) fprintf(stderr, " end=%lld", st[39 * 4 + 1] ? st[39 * 4 + 1] - t0 : -1);
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+    return PP_OK;
+}
+
 int pp_device_info(pp_handle e, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes) {
     if (!e) return PP_ERR_ARG;
     hipDeviceProp_t prop;

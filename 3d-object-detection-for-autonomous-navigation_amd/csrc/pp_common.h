@@ -83,7 +83,7 @@ void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, c
 
 const char* layer_kernel_name(const LayerDesc& L);  // template instantiation that will run L
 int launch_layer(const LayerDesc& L, int batch, float* d_box, float* d_cls, float* d_dir, int napl,
-                 hipStream_t s);  // returns 0 or PP_ERR_UNSUPPORTED
+                 hipStream_t s, int ablate = 0);  // returns 0 or PP_ERR_UNSUPPORTED
 
 struct PostParams {
     int batch;

@@ -244,6 +244,17 @@ class Engine:
         self._check(self._lib.pp_get_kernel_times(self._h, cap, names, ms, ctypes.byref(n)), "pp_get_kernel_times")
         return [(names[i].decode(), float(ms[i])) for i in range(min(n.value, cap))]
 
+    def layer_tags(self):
+        n = ctypes.c_int32(0)
+        self._check(self._lib.pp_layer_count(self._h, ctypes.byref(n)), "pp_layer_count")
+        return [self._lib.pp_layer_tag(self._h, i).decode() for i in range(n.value)]
+
+    def bench_layer(self, layer, batch, reps=20, ablate=0):
+        t = ctypes.c_float(0)
+        self._check(self._lib.pp_bench_layer(self._h, int(layer), int(batch), int(reps), int(ablate), ctypes.byref(t)),
+                    "pp_bench_layer")
+        return float(t.value)
+
     def timer_start(self):
         self._check(self._lib.pp_timer_start(self._h), "pp_timer_start")
 

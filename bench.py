@@ -175,7 +175,7 @@ def main():
     dominant = max(kernel_ms, key=kernel_ms.get)
     lf = layer_flops(d, B)
     sb = stage_bytes(d, B, N, float(im_np.mean()))
-    if dominant.startswith("k_gemm_layer"):
+    if dominant.startswith("k_gemm"):
         flops_step = sum(lf[tag.split(":")[1]] for tag in per_layer if tag.startswith(dominant + ":"))
         per_launch = flops_step / launches[dominant]
         avg_ms = kernel_ms[dominant] / launches[dominant]

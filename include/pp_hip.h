@@ -183,6 +183,15 @@ int pp_get_kernel_times(pp_handle h, int32_t capacity, const char** names, float
 int pp_timer_start(pp_handle h);
 int pp_timer_stop(pp_handle h, float* elapsed_ms); /* records, waits, returns the elapsed time */
 
+/* Kernel-tuning aid: runs RPN layer `layer` (0-based, in launch order; the last one is
+ * the heads) `reps` times on whatever the activation buffers hold for `batch` frames and
+ * returns the average launch duration.  `ablate` is a debug bit mask (0 = the real
+ * kernel; bits switch off phases of the GEMM kernel, results are then wrong). */
+int pp_bench_layer(pp_handle h, int32_t layer, int32_t batch, int32_t reps, int32_t ablate, float* avg_ms);
+/* Number of RPN layer launches per forward pass and the tag ("<kernel>:<layer>") of one. */
+int pp_layer_count(pp_handle h, int32_t* count);
+const char* pp_layer_tag(pp_handle h, int32_t layer);
+
 /* Device properties for reports: name (<=255 chars), CU count, bytes of HBM. */
 int pp_device_info(pp_handle h, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes);
 
