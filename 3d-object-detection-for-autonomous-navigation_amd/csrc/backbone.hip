@@ -24,6 +24,8 @@
 // product does not care about.  Depthwise and pointwise are never written to
 // HBM in between.  Workgroup ids are remapped so that consecutive pixel tiles
 // (which share halo rows) land on the same XCD / L2.
+#include <stdio.h>
+
 #include "pp_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -255,24 +257,26 @@ __global__ __launch_bounds__(256) void k_gemm_layer(GemmArgs a) {
 // The epilogue stages each consumer wave's 32 x NT tile through LDS and writes whole
 // channel rows with 16-byte stores (full 128-B lines).  Odd-width separable layers use
 // k_gemm_layer above.
-template <int NT, int MODE, int S>
-__global__ __launch_bounds__(512, 4) void k_gemm_ws(GemmArgs a) {
+template <int NT, int MODE, int S, int PXB>
+__global__ __launch_bounds__(PXB * 4, 4) void k_gemm_ws(GemmArgs a) {
+    constexpr int NCW = PXB / 32;                    // consumer waves == producer waves
+    constexpr int NPT = NCW * 64;                    // producer (and consumer) threads
     constexpr int KCH = (MODE == 0) ? 16 : 32;      // channels per K-chunk
     constexpr int LSTR = KCH + 4;                    // LDS row stride (floats): conflict-free ds_read_b128
     constexpr int G = KCH / 4;                       // float4 channel groups per row
-    constexpr int PXT = PX_TILE * G / 256;           // pixels per producer thread (2 or 4)
+    constexpr int PXT = PXB * G / NPT;               // pixels per producer thread (2 or 4)
     constexpr int WW = (MODE == 0) ? (PXT - 1) * S + 3 : 1;   // input window width
     constexpr int NLD = (MODE == 0) ? 3 * WW : PXT;  // activation float4 loads per thread per chunk
-    constexpr int SA = PX_TILE * LSTR, SB = NT * LSTR;
-    constexpr int NB4 = (NT * G + 255) / 256;        // weight float4 per producer thread per chunk
+    constexpr int SA = PXB * LSTR, SB = NT * LSTR;
+    constexpr int NB4 = (NT * G + NPT - 1) / NPT;    // weight float4 per producer thread per chunk
     constexpr int NTILES = NT / 32;
     constexpr int KQ = KCH / 8;                      // float4 fragment reads per operand per chunk
     // one LDS arena: [sA buf0 | sA buf1 | sB buf0 | sB buf1]; the epilogue re-uses it as the
     // consumers' output staging area
     constexpr int DWMAX = (MODE == 0) ? 9 * 256 : 0;   // depthwise taps [9][cin], cin <= 256 on this path
-    constexpr int ARENA = (2 * SA + 2 * SB + DWMAX > 4 * 32 * NT) ? (2 * SA + 2 * SB + DWMAX) : (4 * 32 * NT);
+    constexpr int ARENA = (2 * SA + 2 * SB + DWMAX > PXB * NT) ? (2 * SA + 2 * SB + DWMAX) : (PXB * NT);
     __shared__ __attribute__((aligned(16))) float smem[ARENA];
-    __shared__ int s_opix[PX_TILE];
+    __shared__ int s_opix[PXB];
     float* const sA = smem;
     float* const sB = smem + 2 * SA;
     float* const sDW = smem + 2 * SA + 2 * SB;
@@ -284,13 +288,13 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ws(GemmArgs a) {
         const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
         mt = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int p0 = mt * PX_TILE;
+    const int p0 = mt * PXB;
     const int n0 = blockIdx.y * NT;
     const int cin = a.cin;
     const int nchunks = cin / KCH;
     const int dbg = a.dbg;
 
-    if (tid < PX_TILE) {   // output pixel index per tile row (deconv: pixel of tap (0,0))
+    if (tid < PXB) {   // output pixel index per tile row (deconv: pixel of tap (0,0))
         const int pix = min(p0 + tid, a.M - 1);
         int o = pix;
         if (a.epi == 1) {
@@ -303,13 +307,13 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ws(GemmArgs a) {
     }
 
     if (MODE == 0) {   // depthwise taps of the whole layer -> LDS once (visible after the first barrier)
-        for (int e = tid; e < 9 * cin / 4; e += 512)
+        for (int e = tid; e < 9 * cin / 4; e += 2 * NPT)
             reinterpret_cast<float4*>(sDW)[e] = reinterpret_cast<const float4*>(a.dw)[e];
     }
 
-    if (wave >= 4) {
+    if (wave >= NCW) {
         // =============================== producers ===============================
-        const int pt = tid - 256;
+        const int pt = tid - NPT;
         const int c4 = pt % G, q = pt / G;            // channel group, pixel group
         const int pix0 = p0 + PXT * q;                // first of this thread's pixels (M % PXT == 0)
         const bool pvalid = pix0 < a.M;
@@ -341,9 +345,9 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ws(GemmArgs a) {
         }
         const int rs4 = a.in_w * cin * 4, cin4 = cin * 4;   // row / pixel stride in bytes (uniform)
         float4 rin[NLD];
-        float4 rb0, rb1, rb2, rb3;   // weight prefetch (named scalars: an array here ended up in scratch)
-        rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-        static_assert(NB4 <= 4, "weight prefetch registers");
+        float4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;   // weight prefetch (named scalars: an array ended up in scratch)
+        rb0 = rb1 = rb2 = rb3 = rb4 = rb5 = rb6 = rb7 = make_float4(0.f, 0.f, 0.f, 0.f);
+        static_assert(NB4 <= 8, "weight prefetch registers");
         float* const dA = sA + (PXT * q) * LSTR + c4 * 4;
 
         // (a macro, not a lambda: by-reference captures of rin / rb kept those arrays in scratch memory)
@@ -357,18 +361,19 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ws(GemmArgs a) {
                 rin[e] = *reinterpret_cast<const float4*>(inb + (cbase + chb_ + (unsigned)rel_));        \
             }                                                                                            \
             WS_LOAD_B(0, rb0, KCIDX) WS_LOAD_B(1, rb1, KCIDX) WS_LOAD_B(2, rb2, KCIDX) WS_LOAD_B(3, rb3, KCIDX) \
+            WS_LOAD_B(4, rb4, KCIDX) WS_LOAD_B(5, rb5, KCIDX) WS_LOAD_B(6, rb6, KCIDX) WS_LOAD_B(7, rb7, KCIDX) \
         }
 #define WS_LOAD_B(R, REG, KCIDX)                                                                         \
         if (NB4 > (R)) {                                                                                 \
-            const int e_ = pt + 256 * (R);                                                               \
-            if ((NT * G) % 256 == 0 || e_ < NT * G)                                                      \
+            const int e_ = pt + NPT * (R);                                                               \
+            if ((NT * G) % NPT == 0 || e_ < NT * G)                                                      \
                 REG = *reinterpret_cast<const float4*>(                                                  \
                     wtb + (unsigned)(((n0 + e_ / G) * cin + (KCIDX) * KCH + (e_ % G) * 4) * 4));         \
         }
 #define WS_STORE_B(R, REG)                                                                               \
         if (NB4 > (R)) {                                                                                 \
-            const int e_ = pt + 256 * (R);                                                               \
-            if ((NT * G) % 256 == 0 || e_ < NT * G)                                                      \
+            const int e_ = pt + NPT * (R);                                                               \
+            if ((NT * G) % NPT == 0 || e_ < NT * G)                                                      \
                 *reinterpret_cast<float4*>(sB + buf * SB + (e_ / G) * LSTR + (e_ % G) * 4) = REG;        \
         }
         // s = -1 is the pipeline prologue (nothing staged yet)
@@ -423,6 +428,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_ws(GemmArgs a) {
                     }
                 }
                 WS_STORE_B(0, rb0) WS_STORE_B(1, rb1) WS_STORE_B(2, rb2) WS_STORE_B(3, rb3)
+                WS_STORE_B(4, rb4) WS_STORE_B(5, rb5) WS_STORE_B(6, rb6) WS_STORE_B(7, rb7)
                 if (stamp && s + 1 < 40) st[(s + 1) * 4 + 1] = clock64();
                 // ---- issue the loads of chunk s+2 ----
                 if (s + 2 < nchunks) WS_LOAD_CHUNK(s + 2)
@@ -532,11 +538,24 @@ static void launch_t(const GemmArgs& a, int n_total, hipStream_t s) {
     hipLaunchKernelGGL((k_gemm_layer<NT, MODE>), grid, dim3(256), 0, s, a);
 }
 
+// 128-pixel tiles (8-wave workgroups: every SIMD hosts one consumer and one producer wave) are the
+// default.  64-pixel tiles (4-wave workgroups) are used only when a launch would otherwise not even
+// cover the chip's CUs once (small batches): measured at B=64 they are slower -- a 4-wave
+// workgroup's two consumer waves land on two of the four SIMDs, so the matrix pipes are unevenly fed.
+static bool ws_small_tile(long long M, int n_total, int NT) {
+    const long long tiles128 = ((M + 127) / 128) * (n_total / NT);
+    return tiles128 < 256;
+}
+
 template <int NT, int MODE, int S>
 static void launch_ws(const GemmArgs& a, int n_total, hipStream_t s) {
-    const unsigned mt = (unsigned)((a.M + PX_TILE - 1) / PX_TILE);
-    dim3 grid(mt, n_total / NT);
-    hipLaunchKernelGGL((k_gemm_ws<NT, MODE, S>), grid, dim3(512), 0, s, a);
+    if (ws_small_tile(a.M, n_total, NT)) {
+        dim3 grid((unsigned)((a.M + 63) / 64), n_total / NT);
+        hipLaunchKernelGGL((k_gemm_ws<NT, MODE, S, 64>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((unsigned)((a.M + 127) / 128), n_total / NT);
+        hipLaunchKernelGGL((k_gemm_ws<NT, MODE, S, 128>), grid, dim3(512), 0, s, a);
+    }
 }
 
 long long* g_stamps = nullptr;   // tuning aid: device buffer for in-kernel stamps (pp_bench_layer, ablate & 64)
@@ -549,17 +568,22 @@ static bool use_ws(const LayerDesc& L) {
     return (L.stride == 1 || L.stride == 2) && (L.out_w % 2 == 0);
 }
 
-const char* layer_kernel_name(const LayerDesc& L) {
+static long long layer_rows(const LayerDesc& L, int batch) {
+    return (L.kind == LAYER_SEP) ? (long long)batch * L.out_h * L.out_w : (long long)batch * L.in_h * L.in_w;
+}
+
+// name of the template instantiation that runs layer L at this batch size (profiler tags)
+std::string layer_kernel_name(const LayerDesc& L, int batch) {
     const int nt = (L.kind == LAYER_HEAD) ? 32 : (L.cout % 128 == 0 ? 128 : (L.cout % 64 == 0 ? 64 : 32));
+    const int mode = (L.kind == LAYER_SEP) ? 0 : 1;
+    char buf[64];
     if (use_ws(L)) {
-        if (L.kind == LAYER_SEP) {
-            if (L.stride == 1) return nt == 128 ? "k_gemm_ws<128,0,1>" : (nt == 64 ? "k_gemm_ws<64,0,1>" : "k_gemm_ws<32,0,1>");
-            return nt == 128 ? "k_gemm_ws<128,0,2>" : (nt == 64 ? "k_gemm_ws<64,0,2>" : "k_gemm_ws<32,0,2>");
-        }
-        return nt == 128 ? "k_gemm_ws<128,1,1>" : (nt == 64 ? "k_gemm_ws<64,1,1>" : "k_gemm_ws<32,1,1>");
+        const int pxb = ws_small_tile(layer_rows(L, batch), L.n_total, nt) ? 64 : 128;
+        snprintf(buf, sizeof(buf), "k_gemm_ws<%d,%d,%d,%d>", nt, mode, mode == 0 ? L.stride : 1, pxb);
+    } else {
+        snprintf(buf, sizeof(buf), "k_gemm_layer<%d,%d>", nt, mode);
     }
-    if (L.kind == LAYER_SEP) return nt == 128 ? "k_gemm_layer<128,0>" : (nt == 64 ? "k_gemm_layer<64,0>" : "k_gemm_layer<32,0>");
-    return nt == 128 ? "k_gemm_layer<128,1>" : (nt == 64 ? "k_gemm_layer<64,1>" : "k_gemm_layer<32,1>");
+    return std::string(buf);
 }
 
 int launch_layer(const LayerDesc& L, int batch, float* d_box, float* d_cls, float* d_dir, int napl,

@@ -60,7 +60,8 @@ struct pp_engine {
     pp_detection* h_dets = nullptr;  // pinned
     int* h_ndets = nullptr;          // pinned
     std::vector<LayerDesc> layers;
-    std::vector<std::string> layer_tags;  // "<kernel symbol>:<layer>" for the profiler
+    std::vector<std::string> layer_tags;  // "<kernel symbol>:<layer>" for the profiler (for batch tag_batch)
+    int tag_batch = -1;
 
     // compat scratch (grow-only)
     float* d_voxels = nullptr; size_t cap_voxels = 0;
@@ -253,7 +254,15 @@ int run_anchor_mask(pp_engine* e, int batch) {
     return PP_OK;
 }
 
+void refresh_tags(pp_engine* e, int batch) {
+    if (e->tag_batch == batch) return;
+    for (size_t i = 0; i < e->layers.size(); ++i)
+        e->layer_tags[i] = layer_kernel_name(e->layers[i], batch) + ":" + e->layers[i].name;
+    e->tag_batch = batch;
+}
+
 int run_backbone(pp_engine* e, int batch) {
+    refresh_tags(e, batch);
     for (size_t i = 0; i < e->layers.size(); ++i) {
         const LayerDesc& L = e->layers[i];
         ProfScope ps(e, e->layer_tags[i].c_str());
@@ -451,7 +460,7 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
         }
         // wire activation buffers: ping-pong inside the blocks, deconvs into the concat buffer
         if (st2 == PP_OK) {
-            for (const LayerDesc& L : e->layers) e->layer_tags.push_back(std::string(layer_kernel_name(L)) + ":" + L.name);
+            e->layer_tags.assign(e->layers.size(), std::string());
             const float* cur = e->d_canvas;
             int pp = 0;
             for (LayerDesc& L : e->layers) {
@@ -862,6 +871,7 @@ int pp_layer_count(pp_handle e, int32_t* count) {
 
 const char* pp_layer_tag(pp_handle e, int32_t layer) {
     if (!e || layer < 0 || layer >= (int)e->layer_tags.size()) return "";
+    refresh_tags(e, e->cur_batch > 0 ? e->cur_batch : e->B);
     return e->layer_tags[layer].c_str();
 }
 

@@ -81,7 +81,7 @@ int launch_pfn(const PfnParams& p, bool padded_source, hipStream_t s);  // retur
 void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, const int* cells, int64_t A,
                         float threshold, int* integ, uint8_t* mask, hipStream_t s);
 
-const char* layer_kernel_name(const LayerDesc& L);  // template instantiation that will run L
+std::string layer_kernel_name(const LayerDesc& L, int batch);  // template instantiation that runs L at this batch
 int launch_layer(const LayerDesc& L, int batch, float* d_box, float* d_cls, float* d_dir, int napl,
                  hipStream_t s, int ablate = 0);  // returns 0 or PP_ERR_UNSUPPORTED
 

@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight per GPU: each has its own engine handle (stream + workspaces), steps "
+                         "alternate between them so the latency-bound front of one step (voxelise, PFN, NMS) "
+                         "overlaps the MFMA-bound backbone of the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-b1", action="store_true",
                     help="also measure batch-1 latency (separate engine; off by default so that the "
@@ -121,28 +125,33 @@ def main():
     pp._lib.lib()  # fails loudly if the HIP library is missing
     B, N = args.batch, args.points
     cfg = pp.config.pedestrian_d435i_config(B)
-    eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=max(N, 4096), device=local_rank)
+    engines = [pp.Engine(cfg, max_batch=B, max_points_per_frame=max(N, 4096), device=local_rank)
+               for _ in range(max(1, args.inflight))]
+    eng = engines[0]
     d = eng.d
     weights = pp.weights.init_weights(d, seed=7)
-    eng.load_weights(weights)
     calib = pp.synth.default_calib()
     frame_ids = pp.frame_shard.rank_frames(rank, n_gpus, B)     # this rank's frames (weak scaling)
     frames = [pp.synth.d435i_cloud(i, N, d.num_point_features) for i in frame_ids]
-    eng.upload(frames, np.stack([calib[0]] * B), np.stack([calib[1]] * B))   # points now resident in HBM
+    for e in engines:
+        e.load_weights(weights)
+        e.upload(frames, np.stack([calib[0]] * B), np.stack([calib[1]] * B))   # points now resident in HBM
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.detect_async()
-    eng.sync()
+    for i in range(args.warmup):
+        engines[i % len(engines)].detect_async()
+    for e in engines:
+        e.sync()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.detect_async()
-    eng.sync()
+    for i in range(args.steps):
+        engines[i % len(engines)].detect_async()
+    for e in engines:
+        e.sync()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -153,14 +162,16 @@ def main():
     dets, n_det = eng.detections()
     im_np = eng.intermediates()["n_pillars"]
 
-    # ---- per-kernel durations (HIP events on the engine's stream), same process ----
-    eng.set_profiling(True)
+    # ---- per-kernel durations (HIP events on each engine's own stream), same process, same
+    # alternating pattern as the timed region so that overlap between in-flight batches is included ----
+    for e in engines:
+        e.set_profiling(True)
     agg, per_layer = {}, {}
-    prof_steps = max(3, min(10, args.steps))
-    for _ in range(prof_steps):
-        eng.detect_async()
-        eng.sync()
-        for tag, ms in eng.kernel_times():
+    prof_steps = max(4, min(12, args.steps))
+
+    def collect(e):
+        e.sync()
+        for tag, ms in e.kernel_times():
             sym, _, layer = tag.partition(":")
             a = agg.setdefault(sym, [0.0, 0])
             a[0] += ms
@@ -169,7 +180,19 @@ def main():
                 pl = per_layer.setdefault(tag, [0.0, 0])
                 pl[0] += ms
                 pl[1] += 1
-    eng.set_profiling(False)
+
+    pending = []
+    for i in range(prof_steps):
+        e = engines[i % len(engines)]
+        if e in pending:
+            collect(e)
+            pending.remove(e)
+        e.detect_async()
+        pending.append(e)
+    for e in pending:
+        collect(e)
+    for e in engines:
+        e.set_profiling(False)
     kernel_ms = {k: v[0] / prof_steps for k, v in agg.items()}        # per step
     launches = {k: v[1] / prof_steps for k, v in agg.items()}
     dominant = max(kernel_ms, key=kernel_ms.get)
@@ -192,6 +215,18 @@ def main():
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
                     "launches_per_step": launches[dominant], "algorithmic_bytes_per_launch": per_launch}
+    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/*pmc_traffic.json;
+    # rocprofv3 cannot run inside this process), per launch like `achieved`
+    try:
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+        if pmc_files:
+            pmc = json.load(open(pmc_files[-1]))["kernels"].get(dominant)
+            if pmc:
+                roofline["traffic"] = pmc["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = os.path.basename(pmc_files[-1])
+    except Exception:
+        pass
     gpu_ms = sum(kernel_ms.values())
     total_flops = sum(lf.values())
     extras = {
@@ -239,6 +274,7 @@ def main():
                                    f"B={B} frames/GPU x {N} pts, raw points -> detections end to end "
                                    f"(BASELINE.json configs[1]); points resident in HBM",
                        "batch_per_gpu": B, "points_per_frame": N, "parallelism": f"frame-parallel x{n_gpus}, no collective",
+                       "batches_in_flight_per_gpu": len(engines),
                        "mean_pillars_per_frame": float(im_np.mean()), "mean_detections_per_frame": float(n_det.mean()),
                        "device": info["name"], "compute_units": info["compute_units"]},
             "p50_ms_per_step": p50_step,
@@ -249,7 +285,8 @@ def main():
             "detail": extras,
         }
         print(json.dumps(line))
-    eng.close()
+    for e in engines:
+        e.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

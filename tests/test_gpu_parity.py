@@ -204,6 +204,50 @@ def test_predict_nms_conventions(pp, engines):
     assert (40 * d.head_w + 50) * 2 + 1 in kept
 
 
+@pytest.mark.parametrize("score_thr,pre_max,post_max", [(0.55, 100, 50), (0.0, 30, 7), (0.3, 1000, 5)])
+def test_predict_thresholds_and_caps(pp, engines, score_thr, pre_max, post_max):
+    """nms_score_threshold > 0, nms_pre_max_size < 100 and small post caps (config-driven branches
+    of model/voxelnet.py:1193-1203 and libraries/eval_helper_functions.py:470-486)."""
+    cfg = pp.config.pedestrian_d435i_config(1)
+    s = cfg["model"]["second"]
+    s["nms_score_threshold"], s["nms_pre_max_size"], s["nms_post_max_size"] = score_thr, pre_max, post_max
+    eng = engines(f"net-A1-thr{score_thr}-{pre_max}-{post_max}", cfg, max_batch=1)
+    d = eng.d
+    rng = np.random.default_rng(int(score_thr * 100) + pre_max)
+    box = (rng.standard_normal((1, d.head_h, d.head_w, 14)) * 0.3).astype(np.float32)
+    cls = (rng.standard_normal((1, d.head_h, d.head_w, 2)) * 0.8).astype(np.float32)
+    dr = rng.standard_normal((1, d.head_h, d.head_w, 4)).astype(np.float32)
+    mask = (rng.random((1, d.num_anchors)) < 0.6).astype(np.uint8)
+    rect, trv, _ = pp.synth.default_calib()
+    dets, n = eng.predict(box, cls, dr, mask, rect[None], trv[None])
+    ex = (None, None, None, rect[None], trv[None], None, eng.anchors[None], mask, np.array([0]), None)
+    ref = rn.predict(ex, {"box_preds": box, "cls_preds": cls, "dir_cls_preds": dr}, d.nms_dict())[0]
+    assert ref["scores"] is not None and n[0] == len(ref["scores"]) <= post_max
+    np.testing.assert_allclose(dets[0]["score"][:n[0]], ref["scores"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dets[0]["box3d_lidar"][:n[0]], ref["box3d_lidar"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dets[0]["box3d_camera"][:n[0]], ref["box3d_camera"], rtol=1e-5, atol=1e-5)
+    if score_thr > 0:
+        assert (dets[0]["score"][:n[0]] >= score_thr).all()
+
+
+def test_config0_variant_t100_12000(pp, engines):
+    """BASELINE.json configs[0] as stated: 12000-pillar cap, 100 points per pillar."""
+    cfg = pp.config.pedestrian_d435i_config(1, max_points=100, max_voxels=12000)
+    eng = engines("net-A1-T100", cfg, max_batch=1, weights_seed=7)
+    d = eng.d
+    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=7))
+    frames = [pp.synth.d435i_cloud(77)]
+    rect, trv, p2 = pp.synth.default_calib()
+    ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
+    dets, n = eng.detect(frames, rect[None], trv[None])
+    im = eng.intermediates()
+    P = ref["frames"][0]["coordinates"].shape[0]
+    assert im["n_pillars"][0] == P and np.array_equal(im["num_points"][0, :P], ref["frames"][0]["num_points"])
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=TOL, atol=TOL)
+    _assert_dets([pp.VoxelNet._to_dict(dets[0], int(n[0]), 0)], ref["dets"])
+
+
 # ------------------------------------------------------------------ fused path, end to end
 @pytest.mark.parametrize("name", ["tiny", "A"])
 def test_fused_detect_matches_oracle_end_to_end(pp, engines, name):
