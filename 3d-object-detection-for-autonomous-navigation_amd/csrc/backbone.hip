@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_gemm_layer(GemmArgs a) {
 // channel rows with 16-byte stores (full 128-B lines).  Odd-width separable layers use
 // k_gemm_layer above.
 template <int NT, int MODE, int S, int PXB>
-__global__ __launch_bounds__(PXB * 4, 4) void k_gemm_ws(GemmArgs a) {
+__global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2 && NT == 128) ? 3 : 4) void k_gemm_ws(GemmArgs a) {
     constexpr int NCW = PXB / 32;                    // consumer waves == producer waves
     constexpr int NPT = NCW * 64;                    // producer (and consumer) threads
     constexpr int KCH = (MODE == 0) ? 16 : 32;      // channels per K-chunk
@@ -319,10 +319,12 @@ __global__ __launch_bounds__(PXB * 4, 4) void k_gemm_ws(GemmArgs a) {
         const bool pvalid = pix0 < a.M;
         const int pc = pvalid ? pix0 : 0;
         // addressing: uniform base pointer + 32-bit BYTE offsets (saddr + voffset loads: one VGPR per
-        // address).  cbase = this thread's first pixel (MODE 0: the centre (dy=1,dx=1) of its window),
-        // always inside the map; an out-of-map window element reads the centre instead and is zeroed
-        // when it is consumed (a select on the LOADED value would serialise the loads).
-        const char* const inb = reinterpret_cast<const char*>(a.in);
+        // address).  Every activation buffer is allocated with a zeroed PP_ZPAD_FLOATS header in front
+        // of its data (pp_api.hip); an out-of-map window element (zero padding of the convolution, or a
+        // pixel past the end of the last tile) simply loads from that header, so no value is ever
+        // selected after the load (a select on the LOADED value would serialise the loads, and masking
+        // at use costs 4 v_cndmask per element).
+        const char* const inb = reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4;
         const char* const wtb = reinterpret_cast<const char*>(a.wt);
         unsigned cbase;
         unsigned okmask = 0;                          // bit dy*WW+dx: that window element is inside the map
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(PXB * 4, 4) void k_gemm_ws(GemmArgs a) {
             const int rem = pc - b * hw;
             const int y = rem / a.px_w, x0 = rem - y * a.px_w;
             const int yi = y * S - 1, xi = x0 * S - 1;
-            cbase = (unsigned)(((b * a.in_h + y * S) * a.in_w + x0 * S) * cin) * 4u;
+            cbase = (unsigned)(((b * a.in_h + y * S) * a.in_w + x0 * S) * cin) * 4u + PP_ZPAD_FLOATS * 4u;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(PXB * 4, 4) void k_gemm_ws(GemmArgs a) {
                     if (pvalid && yi + dy >= 0 && yi + dy < a.in_h && xi + dx >= 0 && xi + dx < a.in_w && !(dbg & 8))
                         okmask |= 1u << (dy * WW + dx);
         } else {
-            cbase = (unsigned)(pc * cin) * 4u;
+            cbase = (unsigned)(pc * cin) * 4u + PP_ZPAD_FLOATS * 4u;
             if (pvalid && !(dbg & 8)) okmask = 1u;
         }
         const int rs4 = a.in_w * cin * 4, cin4 = cin * 4;   // row / pixel stride in bytes (uniform)
@@ -355,10 +357,10 @@ __global__ __launch_bounds__(PXB * 4, 4) void k_gemm_ws(GemmArgs a) {
         {                                                                                                \
             const unsigned chb_ = (unsigned)((KCIDX) * KCH + c4 * 4) * 4u;                               \
             _Pragma("unroll") for (int e = 0; e < NLD; ++e) {                                            \
-                int rel_;                                                                                \
-                if (MODE == 0) rel_ = ((okmask >> e) & 1u) ? ((e / WW - 1) * rs4 + (e % WW - 1) * cin4) : 0; \
-                else rel_ = e * cin4;                                                                    \
-                rin[e] = *reinterpret_cast<const float4*>(inb + (cbase + chb_ + (unsigned)rel_));        \
+                unsigned off_;   /* out-of-map -> the zero header (offset = channel offset only) */     \
+                if (MODE == 0) off_ = ((okmask >> e) & 1u) ? cbase + (unsigned)((e / WW - 1) * rs4 + (e % WW - 1) * cin4) : 0u; \
+                else off_ = okmask ? cbase + (unsigned)(e * cin4) : 0u;                                  \
+                rin[e] = *reinterpret_cast<const float4*>(inb + (off_ + chb_));                          \
             }                                                                                            \
             WS_LOAD_B(0, rb0, KCIDX) WS_LOAD_B(1, rb1, KCIDX) WS_LOAD_B(2, rb2, KCIDX) WS_LOAD_B(3, rb3, KCIDX) \
             WS_LOAD_B(4, rb4, KCIDX) WS_LOAD_B(5, rb5, KCIDX) WS_LOAD_B(6, rb6, KCIDX) WS_LOAD_B(7, rb7, KCIDX) \
@@ -387,6 +389,10 @@ __global__ __launch_bounds__(PXB * 4, 4) void k_gemm_ws(GemmArgs a) {
         long long* st = a.stamps ? a.stamps + ((size_t)blockIdx.x * 2 + 1) * 40 * 4 : nullptr;
         for (int s = -1; s < nchunks; ++s) {
             if (stamp && s + 1 < 40) st[(s + 1) * 4 + 0] = clock64();
+            if ((dbg & 64) && a.stamps != nullptr && blockIdx.x < 64 && blockIdx.y == 0 && wave == NCW) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic build only: isolate the load wait
+                if (stamp && s + 1 < 40) st[(s + 1) * 4 + 1] = clock64();
+            }
             if (s + 1 < nchunks) {
                 // ---- stage chunk s+1 (registers -> LDS buffer (s+1)&1) ----
                 const int kc = s + 1, buf = kc & 1;
@@ -396,9 +402,6 @@ __global__ __launch_bounds__(PXB * 4, 4) void k_gemm_ws(GemmArgs a) {
                     float4 o[PXT];
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int e = 0; e < NLD; ++e)
-                        if (!((okmask >> e) & 1u)) { rin[e].x = 0.f; rin[e].y = 0.f; rin[e].z = 0.f; rin[e].w = 0.f; }
                     if (!(dbg & 2)) {
 #pragma unroll
                         for (int dy = 0; dy < 3; ++dy)
@@ -418,22 +421,20 @@ __global__ __launch_bounds__(PXB * 4, 4) void k_gemm_ws(GemmArgs a) {
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) *reinterpret_cast<float4*>(dst + j * LSTR) = o[j];
                 } else {
-                    const float km = okmask ? 1.f : 0.f;   // (a ?: between two float4 lvalues would force rin into memory)
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) {
-                        float4 t = rin[j];
-                        if (!okmask) { t.x = 0.f; t.y = 0.f; t.z = 0.f; t.w = 0.f; }
-                        (void)km;
+                        // element-wise rebuild: a whole-struct copy from rin[] becomes a private->LDS
+                        // memcpy that keeps the array in scratch memory
+                        const float4 t = make_float4(rin[j].x, rin[j].y, rin[j].z, rin[j].w);
                         *reinterpret_cast<float4*>(dst + j * LSTR) = t;
                     }
                 }
                 WS_STORE_B(0, rb0) WS_STORE_B(1, rb1) WS_STORE_B(2, rb2) WS_STORE_B(3, rb3)
                 WS_STORE_B(4, rb4) WS_STORE_B(5, rb5) WS_STORE_B(6, rb6) WS_STORE_B(7, rb7)
-                if (stamp && s + 1 < 40) st[(s + 1) * 4 + 1] = clock64();
+                if (stamp && s + 1 < 40) st[(s + 1) * 4 + 2] = clock64();
                 // ---- issue the loads of chunk s+2 ----
                 if (s + 2 < nchunks) WS_LOAD_CHUNK(s + 2)
             }
-            if (stamp && s + 1 < 40) st[(s + 1) * 4 + 2] = clock64();
             __syncthreads();
             if (stamp && s + 1 < 40) st[(s + 1) * 4 + 3] = clock64();
         }

@@ -432,10 +432,17 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             A1(dalloc(q, &e->d_pcell, BMV));
             A1(dalloc(q, &e->d_npillars, (size_t)e->B));
             A1(dalloc(q, &e->d_nvalid, (size_t)e->B));
-            A1(dalloc(q, &e->d_canvas, (size_t)e->B * e->ny * e->nx * e->C));
-            A1(dalloc(q, &e->d_act[0], act_max));
-            A1(dalloc(q, &e->d_act[1], act_max));
-            A1(dalloc(q, &e->d_concat, (size_t)e->B * HW * e->CC));
+            // activation buffers carry a zeroed PP_ZPAD_FLOATS header (see backbone.hip producers)
+            auto APAD = [&](float** p, size_t count) {
+                float* raw = nullptr;
+                A1(dalloc(q, &raw, count + PP_ZPAD_FLOATS));
+                if (st2 == PP_OK && hipMemset(raw, 0, PP_ZPAD_FLOATS * sizeof(float)) != hipSuccess) st2 = PP_ERR_HIP;
+                *p = raw ? raw + PP_ZPAD_FLOATS : nullptr;
+            };
+            APAD(&e->d_canvas, (size_t)e->B * e->ny * e->nx * e->C);
+            APAD(&e->d_act[0], act_max);
+            APAD(&e->d_act[1], act_max);
+            APAD(&e->d_concat, (size_t)e->B * HW * e->CC);
             A1(dalloc(q, &e->d_box, (size_t)e->B * HW * e->napl * 7));
             A1(dalloc(q, &e->d_cls, (size_t)e->B * HW * e->napl));
             A1(dalloc(q, &e->d_dir, (size_t)e->B * HW * e->napl * 2));

@@ -12,6 +12,9 @@
 #include "../../include/pp_hip.h"
 
 #define PP_WAVE 64
+// zeroed floats in front of every activation buffer (>= the widest layer input, 384 channels):
+// the GEMM producers read convolution zero-padding from there instead of masking loaded values
+#define PP_ZPAD_FLOATS 512
 
 // ----- voxel grid geometry (float64, as the reference's index math) -----
 struct VoxGeom {
