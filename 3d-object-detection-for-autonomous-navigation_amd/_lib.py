@@ -15,8 +15,10 @@ _CSRC = os.path.join(_PKG, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_PKG), "include", "pp_hip.h")
 SO_PATH = os.path.join(_PKG, "libpp_hip.so")
 SOURCES = ["pp_api.hip", "voxelize.hip", "pfn.hip", "anchor_mask.hip", "backbone.hip", "postprocess.hip"]
+# -fno-slp-vectorize: keeps f32 FMAs as v_fma_f32; the SLP vectoriser's v_pk_fma_f32 is slow on a SIMD
+# that is also issuing MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
-               "-Wall", "-Wno-unused-function"]
+               "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 EXPORTS = [
     "pp_abi_version", "pp_create", "pp_destroy", "pp_last_error", "pp_set_weight", "pp_finalize_weights",

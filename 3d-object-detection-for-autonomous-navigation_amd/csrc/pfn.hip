@@ -19,6 +19,15 @@
 // (coalesced through the CSR index list) and broadcast with v_readlane, the
 // per-pillar max is a running register max.  HBM-bound: reads 4F bytes per
 // point + the cell map, writes 4C bytes per canvas cell.
+//
+// Arithmetic: the dense layer is linear in the 8 decorated features, so per
+// pillar the terms that do not depend on the point are folded into a constant:
+//   sum_k W_k f_k = (W_x + W_cx + W_px) x' + (W_y + W_cy + W_py) y' + (W_z + W_cz) z [+ W_i i] + K
+//   x' = x - pillar_centre_x (the reference's f_center, small), K = b + W_x cx + W_y cy
+//        - W_cx (mean_x - cx) - W_cy (mean_y - cy) - W_cz mean_z
+// (3-4 FMAs per point and channel instead of 8-9; working in pillar-local x', y'
+// keeps every product small, so the rounding error stays below the reference's
+// own evaluation of the raw-coordinate terms), and max_j ReLU(a_j) = ReLU(max_j a_j).
 #include "pp_common.h"
 
 template <int N>
@@ -34,15 +43,18 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// cells per wavefront: pillars hold 1..T points, so a tile's cost varies by 100x; small tiles keep
+// the heaviest wave short (the kernel ends with its slowest wave)
+#define PFN_CW 4
 template <int CPL, int F, bool PADDED>
 __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
     constexpr int FA = F + 5;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int ncanvas = p.ny * p.nx;
-    const int cell0 = (blockIdx.x * 4 + wave) * 16;
+    const int cell0 = (blockIdx.x * 4 + wave) * PFN_CW;
     if (cell0 >= ncanvas) return;
-    const int ncells = min(16, ncanvas - cell0);
+    const int ncells = min(PFN_CW, ncanvas - cell0);
     const int C = p.C;
     const int ch0 = lane * CPL;
     const bool ch_ok = ch0 < C;
@@ -55,12 +67,20 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
         for (int q = 0; q < CPL; ++q) w[k][q] = ch_ok ? p.w[k * C + ch0 + q] : 0.f;
 #pragma unroll
     for (int q = 0; q < CPL; ++q) bias[q] = ch_ok ? p.bias[ch0 + q] : 0.f;
+    // folded per-coordinate weights: raw + cluster-offset + centre-offset columns
+    float wsx[CPL], wsy[CPL], wsz[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        wsx[q] = (w[0][q] + w[F + 0][q]) + w[F + 3][q];
+        wsy[q] = (w[1][q] + w[F + 1][q]) + w[F + 4][q];
+        wsz[q] = w[2][q] + w[F + 2][q];
+    }
 
     const int* map = p.cellmap + (size_t)b * p.nz * ncanvas;
     unsigned occ = 0;
     for (int z = 0; z < p.nz; ++z) {
         const int v = (lane < ncells) ? map[(size_t)z * ncanvas + cell0 + lane] : -1;
-        occ |= (unsigned)(__ballot(v >= 0) & 0xffffull);
+        occ |= (unsigned)(__ballot(v >= 0) & ((1ull << PFN_CW) - 1ull));
     }
 
     float* cbase = p.canvas + ((size_t)b * ncanvas + cell0) * C;
@@ -121,10 +141,20 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
             const float fn = (float)n;
             const float mx = sx / fn, my = sy / fn, mz = sz / fn;
 
-            // ---- per point: features -> dense -> (folded BN) -> ReLU -> running max ----
-            float m[CPL];
+            // ---- per pillar constant, then per point 3-4 FMAs + max per channel ----
+            const float dxm = mx - cxf, dym = my - cyf;
+            float kp[CPL], m[CPL];
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) m[q] = 0.f;
+            for (int q = 0; q < CPL; ++q) {
+                float k0 = bias[q];
+                k0 = fmaf(cxf, w[0][q], k0);
+                k0 = fmaf(cyf, w[1][q], k0);
+                k0 = fmaf(-dxm, w[F + 0][q], k0);
+                k0 = fmaf(-dym, w[F + 1][q], k0);
+                k0 = fmaf(-mz, w[F + 2][q], k0);
+                kp[q] = k0;
+                m[q] = -3.0e38f;
+            }
             for (int j0 = 0; j0 < n; j0 += 64) {
                 const int j = j0 + lane;
                 float pt[F];
@@ -135,25 +165,26 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
 #pragma unroll
                     for (int f = 0; f < F; ++f) pt[f] = q[f];
                 }
+                pt[0] = pt[0] - cxf;   // pillar-local coordinates (the reference's f_center features)
+                pt[1] = pt[1] - cyf;
                 const int cnt = min(64, n - j0);
                 for (int jj = 0; jj < cnt; ++jj) {
-                    float ft[FA];
+                    float ft[F];
 #pragma unroll
                     for (int f = 0; f < F; ++f) ft[f] = bcast(pt[f], jj);
-                    ft[F + 0] = ft[0] - mx;
-                    ft[F + 1] = ft[1] - my;
-                    ft[F + 2] = ft[2] - mz;
-                    ft[F + 3] = ft[0] - cxf;
-                    ft[F + 4] = ft[1] - cyf;
 #pragma unroll
                     for (int q = 0; q < CPL; ++q) {
-                        float o = bias[q];
-#pragma unroll
-                        for (int k = 0; k < FA; ++k) o = fmaf(ft[k], w[k][q], o);
-                        m[q] = fmaxf(m[q], fmaxf(o, 0.f));
+                        float o = kp[q];
+                        o = fmaf(ft[0], wsx[q], o);
+                        o = fmaf(ft[1], wsy[q], o);
+                        o = fmaf(ft[2], wsz[q], o);
+                        if (F > 3) o = fmaf(ft[F - 1], w[F - 1][q], o);
+                        m[q] = fmaxf(m[q], o);
                     }
                 }
             }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) m[q] = fmaxf(m[q], 0.f);   // ReLU after the max (monotone)
             if (n < T) {  // zero-padded rows: Dense(0) = 0 -> BN shift -> ReLU
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) m[q] = fmaxf(m[q], fmaxf(bias[q], 0.f));
@@ -182,7 +213,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
 template <int CPL, int F>
 static void launch_pfn_t(const PfnParams& p, bool padded, hipStream_t s) {
     const int ncanvas = p.ny * p.nx;
-    dim3 grid((ncanvas + 63) / 64, p.batch);
+    dim3 grid((ncanvas + 4 * PFN_CW - 1) / (4 * PFN_CW), p.batch);
     if (padded)
         hipLaunchKernelGGL((k_pfn_canvas<CPL, F, true>), grid, dim3(256), 0, s, p);
     else
