@@ -39,10 +39,11 @@ struct GemmArgs {
     const float* dw;
     const float* wt;
     const float* bias;
-    float* out;
-    float* box;
-    float* cls;
-    float* dir;
+    float* out;               // may be NULL when the layer's only consumer is the fused head GEMM
+    float* head;              // fused head map [pixels][PP_HEAD_COLS]
+    const float* head_wt;     // [PP_HEAD_COLS][cout] (deconv with fused heads)
+    const float* head_bias;   // [PP_HEAD_COLS]
+    int head_mode;            // 0: none, 1: head = partial + bias, 2: head += partial
     int M;                // GEMM rows (pixels) < 2^31 (checked by the launcher)
     int dbg;              // tuning aid: ablation bits (pp_bench_layer), 0 in production
     long long* stamps;    // tuning aid (dbg & 64): [block<64][role 2][iter 40][4] shader-clock stamps
@@ -52,7 +53,6 @@ struct GemmArgs {
     int ld_out, co_off;
     int epi;              // 0: bias+ReLU rows; 1: deconv pixel-shuffle; 2: heads
     int k, cout;          // deconv
-    int nb, nc, nd;       // head widths
 };
 
 // D[row][col] of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -93,17 +93,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
             }
         }
     } else {
-        // heads: columns [0,nb) box, [nb,nb+nc) cls, [nb+nc,nb+nc+nd) dir; bias, no activation
+        // heads: one 32-column row per pixel [box | cls | dir | zero pad]; bias, no activation
         const int col = n0 + col_l;
         const float bv = a.bias[col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pix = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (pix >= a.M) continue;
-            const float v = acc[0][r] + bv;
-            if (col < a.nb) a.box[(size_t)pix * a.nb + col] = v;
-            else if (col < a.nb + a.nc) a.cls[(size_t)pix * a.nc + (col - a.nb)] = v;
-            else if (col < a.nb + a.nc + a.nd) a.dir[(size_t)pix * a.nd + (col - a.nb - a.nc)] = v;
+            if (pix < a.M) a.head[(size_t)pix * PP_HEAD_COLS + col] = acc[0][r] + bv;
         }
     }
 }
@@ -273,8 +269,9 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2 && NT == 128) ? 3 : 4
     constexpr int KQ = KCH / 8;                      // float4 fragment reads per operand per chunk
     // one LDS arena: [sA buf0 | sA buf1 | sB buf0 | sB buf1]; the epilogue re-uses it as the
     // consumers' output staging area
+    constexpr int OSTR = NT + 4;                     // output staging row stride (conflict-free b128 reads)
     constexpr int DWMAX = (MODE == 0) ? 9 * 256 : 0;   // depthwise taps [9][cin], cin <= 256 on this path
-    constexpr int ARENA = (2 * SA + 2 * SB + DWMAX > PXB * NT) ? (2 * SA + 2 * SB + DWMAX) : (PXB * NT);
+    constexpr int ARENA = (2 * SA + 2 * SB + DWMAX > PXB * OSTR) ? (2 * SA + 2 * SB + DWMAX) : (PXB * OSTR);
     __shared__ __attribute__((aligned(16))) float smem[ARENA];
     __shared__ int s_opix[PXB];
     float* const sA = smem;
@@ -487,46 +484,78 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2 && NT == 128) ? 3 : 4
         gemm_epilogue<NTILES>(a, acc, p0, n0, wave, lane, s_opix);
         return;
     }
-    // ---- coalesced epilogue: accumulators -> this wave's LDS rows -> 16-byte stores of whole
-    // channel rows (the final barrier of the K loop guarantees nobody still reads the arena) ----
+    // ---- coalesced epilogue: bias + ReLU -> this wave's LDS rows -> 16-byte stores of whole channel
+    // rows (the final barrier of the K loop guarantees nobody still reads the arena) ----
     if (dbg & 4) return;
-    float* so = smem + wave * 32 * NT;
-#pragma unroll
-    for (int n = 0; n < NTILES; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) so[((r & 3) + 8 * (r >> 2) + 4 * h) * NT + n * 32 + r32] = acc[n][r];
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    constexpr int ROW4 = NT / 4;                 // float4 per staged row
-    const int c4 = lane % ROW4;                  // constant per lane: 64 % ROW4 == 0
+    float* so = smem + wave * 32 * OSTR;
     int cbase = n0, delta = 0;
     if (a.epi == 1) {
         const int tap = n0 / a.cout, i = tap / a.k;
         cbase = n0 - tap * a.cout;
         delta = i * (a.px_w * a.k) + (tap - i * a.k);
     }
-    const float4 bv = *reinterpret_cast<const float4*>(a.bias + cbase + c4 * 4);
-    float* dst = a.out + a.co_off + cbase + c4 * 4;
-    // batches of 4 rows-per-lane: all LDS reads first, then the stores (no per-store wait)
 #pragma unroll
-    for (int it0 = 0; it0 < NT / 8; it0 += 4) {
-        float4 v[4];
-        int op[4];
+    for (int n = 0; n < NTILES; ++n) {
+        const float bvn = a.bias[cbase + n * 32 + r32];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = ((it0 + u) * 64 + lane) / ROW4;
-            v[u] = *reinterpret_cast<const float4*>(so + row * NT + c4 * 4);
-            op[u] = s_opix[wave * 32 + row];
+        for (int r = 0; r < 16; ++r)
+            so[((r & 3) + 8 * (r >> 2) + 4 * h) * OSTR + n * 32 + r32] = fmaxf(acc[n][r] + bvn, 0.f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int ROW4 = NT / 4;                 // float4 per staged row
+    if (a.out != nullptr) {
+        const int c4 = lane % ROW4;              // constant per lane: 64 % ROW4 == 0
+        float* dst = a.out + a.co_off + cbase + c4 * 4;
+        // batches of 4 rows-per-lane: all LDS reads first, then the stores (no per-store wait)
+#pragma unroll
+        for (int it0 = 0; it0 < NT / 8; it0 += 4) {
+            float4 v[4];
+            int op[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = ((it0 + u) * 64 + lane) / ROW4;
+                v[u] = *reinterpret_cast<const float4*>(so + row * OSTR + c4 * 4);
+                op[u] = s_opix[wave * 32 + row];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = ((it0 + u) * 64 + lane) / ROW4;
+                if (p0 + wave * 32 + row < a.M)
+                    *reinterpret_cast<float4*>(dst + (size_t)(op[u] + delta) * a.ld_out) = v[u];
+            }
         }
+    }
+    if (a.head_mode != 0) {
+        // ---- fused SSD heads: this tile's 32 x NT activated outputs (one deconv tap: NT == cout) times
+        // the matching [NT x 32] slice of the head kernels, accumulated into the fused head map.  The
+        // three deconv launches run in stream order and every (pixel, column) is touched by exactly one
+        // workgroup per launch, so the read-modify-write needs no atomics and is bit-reproducible. ----
+        f32x16 hacc;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = ((it0 + u) * 64 + lane) / ROW4;
-            float4 w = v[u];
-            w.x = fmaxf(w.x + bv.x, 0.f); w.y = fmaxf(w.y + bv.y, 0.f);
-            w.z = fmaxf(w.z + bv.z, 0.f); w.w = fmaxf(w.w + bv.w, 0.f);
-            if (p0 + wave * 32 + row < a.M)
-                *reinterpret_cast<float4*>(dst + (size_t)(op[u] + delta) * a.ld_out) = w;
+        for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+        const float* hA = so + r32 * OSTR + h * (NT / 2);
+        const float* hB = a.head_wt + (size_t)r32 * NT + h * (NT / 2);
+#pragma unroll
+        for (int q = 0; q < NT / 8; ++q) {
+            const float4 av = *reinterpret_cast<const float4*>(hA + q * 4);
+            const float4 bw = *reinterpret_cast<const float4*>(hB + q * 4);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bw.x, hacc, 0, 0, 0);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bw.y, hacc, 0, 0, 0);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bw.z, hacc, 0, 0, 0);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bw.w, hacc, 0, 0, 0);
+        }
+        const float hb = (a.head_mode == 1) ? a.head_bias[r32] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int prow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (p0 + prow < a.M) {
+                float* hp = a.head + (size_t)(s_opix[prow] + delta) * PP_HEAD_COLS + r32;
+                float v = hacc[r] + hb;
+                if (a.head_mode == 2) v += *hp;
+                *hp = v;
+            }
         }
     }
     if (stamp) st[39 * 4 + 1] = clock64();
@@ -569,6 +598,12 @@ static bool use_ws(const LayerDesc& L) {
     return (L.stride == 1 || L.stride == 2) && (L.out_w % 2 == 0);
 }
 
+// a deconv can carry the fused head GEMM when one workgroup column covers the tap's whole channel
+// range (NT == cout) and the wave-specialised kernel runs it
+bool deconv_can_fuse_heads(const LayerDesc& L) {
+    return L.kind == LAYER_DECONV && (L.cout == 32 || L.cout == 64 || L.cout == 128) && use_ws(L);
+}
+
 static long long layer_rows(const LayerDesc& L, int batch) {
     return (L.kind == LAYER_SEP) ? (long long)batch * L.out_h * L.out_w : (long long)batch * L.in_h * L.in_w;
 }
@@ -587,8 +622,7 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
     return std::string(buf);
 }
 
-int launch_layer(const LayerDesc& L, int batch, float* d_box, float* d_cls, float* d_dir, int napl,
-                 hipStream_t s, int ablate) {
+int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, int ablate) {
     if (batch <= 0) return 0;
     if (L.cin % KC != 0) return PP_ERR_UNSUPPORTED;
     {
@@ -600,11 +634,10 @@ int launch_layer(const LayerDesc& L, int batch, float* d_box, float* d_cls, floa
     a.dbg = ablate;
     a.stamps = g_stamps;
     a.in = L.in; a.dw = L.d_dw; a.wt = L.d_wt; a.bias = L.d_bias; a.out = L.out;
-    a.box = d_box; a.cls = d_cls; a.dir = d_dir;
+    a.head = d_head; a.head_wt = L.d_head_wt; a.head_bias = L.d_head_bias; a.head_mode = L.head_mode;
     a.in_h = L.in_h; a.in_w = L.in_w; a.cin = L.cin;
     a.stride = L.stride; a.ld_out = L.ld_out; a.co_off = L.co_off;
     a.k = L.k; a.cout = L.cout;
-    a.nb = napl * 7; a.nc = napl; a.nd = napl * 2;
     if (L.kind == LAYER_SEP) {
         a.px_h = L.out_h; a.px_w = L.out_w; a.epi = 0;
         a.M = batch * L.out_h * L.out_w;

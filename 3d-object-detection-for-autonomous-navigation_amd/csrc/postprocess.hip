@@ -47,14 +47,21 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const long long A = p.A;
-    const float* cls = p.cls + (size_t)b * A;
+    const int napl = p.napl;
+    const int nb = napl * 7, nc = napl;
+    // fused head map row of pixel px: [box napl*7 | cls napl | dir napl*2 | pad]; anchor a = px*napl + r
+    const float* head = p.head + (size_t)b * (A / napl) * PP_HEAD_COLS;
     const uint8_t* msk = p.mask + (size_t)b * A;
+    auto cls_of = [&](long long a) -> float {
+        const long long px = a / napl;
+        return head[px * PP_HEAD_COLS + nb + (int)(a - px * napl)];
+    };
     const float thr = p.score_thr;
     const int KTOP = 100;  // model/voxelnet.py:1207 (hard-coded)
 
     auto is_cand = [&](long long a, float& logit) -> bool {
         if (msk[a] != 1) return false;
-        logit = cls[a];
+        logit = cls_of(a);
         if (thr > 0.f) {
             const float sc = 1.f / (1.f + expf(-logit));
             if (!(sc >= thr)) return false;
@@ -125,7 +132,9 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     if (tid < K) {
         const unsigned long long key = s_key[s_order[tid]];
         const unsigned a = ~(unsigned)(key & 0xffffffffull);
-        const float* e = p.box + ((size_t)b * A + a) * 7;
+        const unsigned apx = a / (unsigned)napl, ar = a - apx * (unsigned)napl;
+        const float* hrow = head + (size_t)apx * PP_HEAD_COLS;
+        const float* e = hrow + ar * 7;
         const float* an = p.anchors + (size_t)a * 7;
         const float xa = an[0], ya = an[1], wa = an[3], la = an[4], ha = an[5], ra = an[6];
         const float za = __fadd_rn(an[2], __fdiv_rn(ha, 2.f));
@@ -140,9 +149,9 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         zg = __fsub_rn(zg, __fdiv_rn(hg, 2.f));
         s_box[tid][0] = xg; s_box[tid][1] = yg; s_box[tid][2] = zg;
         s_box[tid][3] = wg; s_box[tid][4] = lg; s_box[tid][5] = hg; s_box[tid][6] = rg;
-        const float lgt = cls[a];
+        const float lgt = hrow[nb + ar];
         s_score[tid] = 1.f / (1.f + expf(-lgt));
-        const float* d = p.dir + ((size_t)b * A + a) * 2;
+        const float* d = hrow + nb + nc + ar * 2;
         s_dir[tid] = (d[1] > d[0]) ? 1 : 0;  // np.argmax: first maximum
         s_anchor[tid] = (int)a;
         // corners (-,-),(-,+),(+,+),(+,-) * dims, rotate by [[c,-s],[s,c]], + centre; min/max

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "pp_common.h"
@@ -49,7 +50,8 @@ struct pp_engine {
     float* d_canvas = nullptr;
     float* d_act[2] = {nullptr, nullptr};
     float* d_concat = nullptr;
-    float *d_box = nullptr, *d_cls = nullptr, *d_dir = nullptr;
+    float* d_head = nullptr;      // fused head map [B][H'*W'][PP_HEAD_COLS]
+    bool fuse_heads = false;      // heads computed in the deconv epilogues (no concat buffer, no head launch)
     int* d_integ = nullptr;
     uint8_t* d_mask = nullptr;
     float* d_anchors = nullptr;
@@ -266,7 +268,7 @@ int run_backbone(pp_engine* e, int batch) {
     for (size_t i = 0; i < e->layers.size(); ++i) {
         const LayerDesc& L = e->layers[i];
         ProfScope ps(e, e->layer_tags[i].c_str());
-        int st = launch_layer(L, batch, e->d_box, e->d_cls, e->d_dir, e->napl, e->stream);
+        int st = launch_layer(L, batch, e->d_head, e->stream);
         if (st) return fail(e, st, "layer %s: unsupported shape (cin=%d cout=%d)", L.name, L.cin, L.cout);
     }
     HIPCHK(e, hipGetLastError());
@@ -277,7 +279,7 @@ int run_post(pp_engine* e, int batch) {
     PostParams p;
     p.batch = batch; p.A = e->A; p.pre_max = e->cfg.nms_pre_max_size; p.post_max = e->cfg.nms_post_max_size;
     p.score_thr = e->cfg.nms_score_threshold; p.iou_thr = e->cfg.nms_iou_threshold;
-    p.box = e->d_box; p.cls = e->d_cls; p.dir = e->d_dir; p.mask = e->d_mask; p.anchors = e->d_anchors;
+    p.head = e->d_head; p.napl = e->napl; p.mask = e->d_mask; p.anchors = e->d_anchors;
     p.calib = e->d_calib; p.dets = e->d_dets; p.n_dets = e->d_ndets;
     ProfScope ps(e, "k_postprocess");
     launch_postprocess(p, e->stream);
@@ -304,6 +306,37 @@ int set_offsets(pp_engine* e, const int32_t* off, int batch) {
     e->cur_batch = batch;
     e->cur_max_n = max_n;
     HIPCHK(e, hipMemcpyAsync(e->d_offsets, e->h_offsets.data(), (batch + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    return PP_OK;
+}
+
+// fused head map [pixels][PP_HEAD_COLS] <-> the reference's three NHWC head tensors
+int fetch_heads(pp_engine* e, int batch, float* box, float* cls, float* dir) {
+    const size_t px = (size_t)batch * e->head_h * e->head_w;
+    const int nb = e->napl * 7, nc = e->napl, nd = e->napl * 2;
+    std::vector<float> h(px * PP_HEAD_COLS);
+    HIPCHK(e, hipMemcpyAsync(h.data(), e->d_head, h.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (size_t p = 0; p < px; ++p) {
+        const float* r = h.data() + p * PP_HEAD_COLS;
+        if (box) memcpy(box + p * nb, r, nb * sizeof(float));
+        if (cls) memcpy(cls + p * nc, r + nb, nc * sizeof(float));
+        if (dir) memcpy(dir + p * nd, r + nb + nc, nd * sizeof(float));
+    }
+    return PP_OK;
+}
+
+int upload_heads(pp_engine* e, int batch, const float* box, const float* cls, const float* dir) {
+    const size_t px = (size_t)batch * e->head_h * e->head_w;
+    const int nb = e->napl * 7, nc = e->napl, nd = e->napl * 2;
+    std::vector<float> h(px * PP_HEAD_COLS, 0.f);
+    for (size_t p = 0; p < px; ++p) {
+        float* r = h.data() + p * PP_HEAD_COLS;
+        memcpy(r, box + p * nb, nb * sizeof(float));
+        memcpy(r + nb, cls + p * nc, nc * sizeof(float));
+        memcpy(r + nb + nc, dir + p * nd, nd * sizeof(float));
+    }
+    HIPCHK(e, hipMemcpyAsync(e->d_head, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));   // h is a local
     return PP_OK;
 }
 
@@ -409,6 +442,17 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             e->layers.push_back(D);
         }
         if (st2 == PP_OK) {
+            e->fuse_heads = true;
+            for (const LayerDesc& L : e->layers)
+                if (L.kind == LAYER_DECONV && !deconv_can_fuse_heads(L)) e->fuse_heads = false;
+            if (getenv("PP_NO_HEAD_FUSION")) e->fuse_heads = false;   // A/B switch for measurements
+        }
+        if (st2 == PP_OK && e->fuse_heads) {
+            int nd = 0;
+            for (LayerDesc& L : e->layers)
+                if (L.kind == LAYER_DECONV) L.head_mode = (nd++ == 0) ? 1 : 2;
+        }
+        if (st2 == PP_OK && !e->fuse_heads) {
             LayerDesc H;
             memset(&H, 0, sizeof(H));
             H.kind = LAYER_HEAD; H.cin = e->CC; H.cout = 32; H.in_h = e->head_h; H.in_w = e->head_w;
@@ -442,10 +486,8 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             APAD(&e->d_canvas, (size_t)e->B * e->ny * e->nx * e->C);
             APAD(&e->d_act[0], act_max);
             APAD(&e->d_act[1], act_max);
-            APAD(&e->d_concat, (size_t)e->B * HW * e->CC);
-            A1(dalloc(q, &e->d_box, (size_t)e->B * HW * e->napl * 7));
-            A1(dalloc(q, &e->d_cls, (size_t)e->B * HW * e->napl));
-            A1(dalloc(q, &e->d_dir, (size_t)e->B * HW * e->napl * 2));
+            if (!e->fuse_heads) APAD(&e->d_concat, (size_t)e->B * HW * e->CC);
+            A1(dalloc(q, &e->d_head, (size_t)e->B * HW * PP_HEAD_COLS));
             A1(dalloc(q, &e->d_integ, (size_t)e->B * e->ny * e->nx));
             A1(dalloc(q, &e->d_mask, (size_t)e->B * e->A));
             A1(dalloc(q, &e->d_anchors, (size_t)e->A * 7));
@@ -472,7 +514,7 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             int pp = 0;
             for (LayerDesc& L : e->layers) {
                 if (L.kind == LAYER_SEP) { L.in = cur; L.out = e->d_act[pp]; cur = L.out; pp ^= 1; }
-                else if (L.kind == LAYER_DECONV) { L.in = cur; L.out = e->d_concat; }
+                else if (L.kind == LAYER_DECONV) { L.in = cur; L.out = e->fuse_heads ? nullptr : e->d_concat; }
                 else { L.in = e->d_concat; L.out = nullptr; }
             }
         }
@@ -527,6 +569,26 @@ int pp_finalize_weights(pp_handle e) {
         int st = upload(e, &e->d_pfn_w, w); if (st) return st;
         st = upload(e, &e->d_pfn_b, sh); if (st) return st;
     }
+    // the three head kernels as one [PP_HEAD_COLS][CC] matrix (rows: box | cls | dir | zero pad) + bias
+    std::vector<float> headw((size_t)PP_HEAD_COLS * e->CC, 0.f), headb(PP_HEAD_COLS, 0.f);
+    {
+        const int nb = e->napl * 7, nc = e->napl, nd = e->napl * 2, CC = e->CC;
+        const auto* kb = getw(e, "rpn/conv_box/kernel", {1, 1, CC, nb});
+        const auto* bb = getw(e, "rpn/conv_box/bias", {nb});
+        const auto* kc = getw(e, "rpn/conv_cls/kernel", {1, 1, CC, nc});
+        const auto* bc = getw(e, "rpn/conv_cls/bias", {nc});
+        const auto* kd = getw(e, "rpn/conv_dir_cls/kernel", {1, 1, CC, nd});
+        const auto* bd = getw(e, "rpn/conv_dir_cls/bias", {nd});
+        if (!kb || !bb || !kc || !bc || !kd || !bd) return PP_ERR_SHAPE;
+        for (int ci = 0; ci < CC; ++ci) {
+            for (int o = 0; o < nb; ++o) headw[(size_t)o * CC + ci] = (*kb)[(size_t)ci * nb + o];
+            for (int o = 0; o < nc; ++o) headw[(size_t)(nb + o) * CC + ci] = (*kc)[(size_t)ci * nc + o];
+            for (int o = 0; o < nd; ++o) headw[(size_t)(nb + nc + o) * CC + ci] = (*kd)[(size_t)ci * nd + o];
+        }
+        for (int o = 0; o < nb; ++o) headb[o] = (*bb)[o];
+        for (int o = 0; o < nc; ++o) headb[nb + o] = (*bc)[o];
+        for (int o = 0; o < nd; ++o) headb[nb + nc + o] = (*bd)[o];
+    }
     int bi = 0, li = 0;
     for (LayerDesc& L : e->layers) {
         if (L.kind == LAYER_SEP) {
@@ -552,27 +614,17 @@ int pp_finalize_weights(pp_handle e) {
             }
             int st = upload(e, &L.d_wt, wt); if (st) return st;
             st = upload(e, &L.d_bias, sh); if (st) return st;
+            if (L.head_mode != 0) {   // this branch's [PP_HEAD_COLS][cout] slice of the head matrix
+                std::vector<float> hw((size_t)PP_HEAD_COLS * L.cout);
+                for (int o = 0; o < PP_HEAD_COLS; ++o)
+                    for (int c = 0; c < L.cout; ++c) hw[(size_t)o * L.cout + c] = headw[(size_t)o * e->CC + L.co_off + c];
+                st = upload(e, &L.d_head_wt, hw); if (st) return st;
+                st = upload(e, &L.d_head_bias, headb); if (st) return st;
+            }
             ++bi; li = 0;
         } else {
-            const int nb = e->napl * 7, nc = e->napl, nd = e->napl * 2;
-            const auto* kb = getw(e, "rpn/conv_box/kernel", {1, 1, L.cin, nb});
-            const auto* bb = getw(e, "rpn/conv_box/bias", {nb});
-            const auto* kc = getw(e, "rpn/conv_cls/kernel", {1, 1, L.cin, nc});
-            const auto* bc = getw(e, "rpn/conv_cls/bias", {nc});
-            const auto* kd = getw(e, "rpn/conv_dir_cls/kernel", {1, 1, L.cin, nd});
-            const auto* bd = getw(e, "rpn/conv_dir_cls/bias", {nd});
-            if (!kb || !bb || !kc || !bc || !kd || !bd) return PP_ERR_SHAPE;
-            std::vector<float> wt((size_t)32 * L.cin, 0.f), bias(32, 0.f);
-            for (int ci = 0; ci < L.cin; ++ci) {
-                for (int o = 0; o < nb; ++o) wt[(size_t)o * L.cin + ci] = (*kb)[(size_t)ci * nb + o];
-                for (int o = 0; o < nc; ++o) wt[(size_t)(nb + o) * L.cin + ci] = (*kc)[(size_t)ci * nc + o];
-                for (int o = 0; o < nd; ++o) wt[(size_t)(nb + nc + o) * L.cin + ci] = (*kd)[(size_t)ci * nd + o];
-            }
-            for (int o = 0; o < nb; ++o) bias[o] = (*bb)[o];
-            for (int o = 0; o < nc; ++o) bias[nb + o] = (*bc)[o];
-            for (int o = 0; o < nd; ++o) bias[nb + nc + o] = (*bd)[o];
-            int st = upload(e, &L.d_wt, wt); if (st) return st;
-            st = upload(e, &L.d_bias, bias); if (st) return st;
+            int st = upload(e, &L.d_wt, headw); if (st) return st;
+            st = upload(e, &L.d_bias, headb); if (st) return st;
         }
     }
     e->weights_ready = true;
@@ -756,10 +808,7 @@ int pp_forward_voxels(pp_handle e, const float* voxels, const int32_t* num_point
     prof_reset(e);
     if ((st = run_pfn(e, batch, true, pillar_features ? e->d_feat : nullptr))) return st;
     if ((st = run_backbone(e, batch))) return st;
-    const size_t HW = (size_t)e->head_h * e->head_w;
-    HIPCHK(e, hipMemcpyAsync(box_preds, e->d_box, (size_t)batch * HW * e->napl * 7 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipMemcpyAsync(cls_preds, e->d_cls, (size_t)batch * HW * e->napl * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipMemcpyAsync(dir_cls_preds, e->d_dir, (size_t)batch * HW * e->napl * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if ((st = fetch_heads(e, batch, box_preds, cls_preds, dir_cls_preds))) return st;
     if (pillar_features && P)
         HIPCHK(e, hipMemcpyAsync(pillar_features, e->d_feat, (size_t)P * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     if (canvas)
@@ -778,10 +827,7 @@ int pp_predict(pp_handle e, const float* box_preds, const float* cls_preds, cons
     (void)hipSetDevice(e->device);
     int st = check_batch(e, batch); if (st) return st;
     if ((st = pp_set_calib(e, rect, trv2c, batch))) return st;
-    const size_t HW = (size_t)e->head_h * e->head_w;
-    HIPCHK(e, hipMemcpyAsync(e->d_box, box_preds, (size_t)batch * HW * e->napl * 7 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->d_cls, cls_preds, (size_t)batch * HW * e->napl * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->d_dir, dir_cls_preds, (size_t)batch * HW * e->napl * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if ((st = upload_heads(e, batch, box_preds, cls_preds, dir_cls_preds))) return st;
     HIPCHK(e, hipMemcpyAsync(e->d_mask, anchors_mask, (size_t)batch * e->A, hipMemcpyHostToDevice, e->stream));
     prof_reset(e);
     if ((st = run_post(e, batch))) return st;
@@ -799,7 +845,6 @@ int pp_fetch_intermediates(pp_handle e, int32_t* n_pillars, int32_t* coors, int3
     const int B = e->cur_batch;
     if (B < 1) return fail(e, PP_ERR_STATE, "pp_fetch_intermediates: nothing has run");
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    const size_t HW = (size_t)e->head_h * e->head_w;
     const int MV = e->cfg.max_voxels;
     std::vector<int> np(B);
     HIPCHK(e, hipMemcpy(np.data(), e->d_npillars, B * sizeof(int), hipMemcpyDeviceToHost));
@@ -824,9 +869,10 @@ int pp_fetch_intermediates(pp_handle e, int32_t* n_pillars, int32_t* coors, int3
             }
     }
     if (anchors_mask) HIPCHK(e, hipMemcpy(anchors_mask, e->d_mask, (size_t)B * e->A, hipMemcpyDeviceToHost));
-    if (box_preds) HIPCHK(e, hipMemcpy(box_preds, e->d_box, (size_t)B * HW * e->napl * 7 * sizeof(float), hipMemcpyDeviceToHost));
-    if (cls_preds) HIPCHK(e, hipMemcpy(cls_preds, e->d_cls, (size_t)B * HW * e->napl * sizeof(float), hipMemcpyDeviceToHost));
-    if (dir_cls_preds) HIPCHK(e, hipMemcpy(dir_cls_preds, e->d_dir, (size_t)B * HW * e->napl * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    if (box_preds || cls_preds || dir_cls_preds) {
+        int st = fetch_heads(e, B, box_preds, cls_preds, dir_cls_preds);
+        if (st) return st;
+    }
     if (canvas) HIPCHK(e, hipMemcpy(canvas, e->d_canvas, (size_t)B * e->ny * e->nx * e->C * sizeof(float), hipMemcpyDeviceToHost));
     return PP_OK;
 }
@@ -893,9 +939,9 @@ int pp_bench_layer(pp_handle e, int32_t layer, int32_t batch, int32_t reps, int3
     const LayerDesc& L = e->layers[layer];
     if ((ablate & 64) && !g_stamps) HIPCHK(e, hipMalloc((void**)&g_stamps, 64 * 2 * 40 * 4 * sizeof(long long)));
     for (int i = 0; i < 2; ++i)
-        if ((st = launch_layer(L, batch, e->d_box, e->d_cls, e->d_dir, e->napl, e->stream, ablate))) return fail(e, st, "pp_bench_layer: unsupported layer");
+        if ((st = launch_layer(L, batch, e->d_head, e->stream, ablate))) return fail(e, st, "pp_bench_layer: unsupported layer");
     HIPCHK(e, hipEventRecord(e->t0, e->stream));
-    for (int i = 0; i < reps; ++i) launch_layer(L, batch, e->d_box, e->d_cls, e->d_dir, e->napl, e->stream, ablate);
+    for (int i = 0; i < reps; ++i) launch_layer(L, batch, e->d_head, e->stream, ablate);
     HIPCHK(e, hipEventRecord(e->t1, e->stream));
     HIPCHK(e, hipEventSynchronize(e->t1));
     HIPCHK(e, hipGetLastError());
@@ -906,7 +952,7 @@ int pp_bench_layer(pp_handle e, int32_t layer, int32_t batch, int32_t reps, int3
         const size_t n = 64 * 2 * 40 * 4;
         std::vector<long long> hs(n, 0);
         HIPCHK(e, hipMemsetAsync(g_stamps, 0, n * sizeof(long long), e->stream));
-        launch_layer(L, batch, e->d_box, e->d_cls, e->d_dir, e->napl, e->stream, ablate);
+        launch_layer(L, batch, e->d_head, e->stream, ablate);
         HIPCHK(e, hipMemcpyAsync(hs.data(), g_stamps, n * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(e, hipStreamSynchronize(e->stream));
         for (int blk : {0, 1, 8, 63}) {

@@ -15,6 +15,8 @@
 // zeroed floats in front of every activation buffer (>= the widest layer input, 384 channels):
 // the GEMM producers read convolution zero-padding from there instead of masking loaded values
 #define PP_ZPAD_FLOATS 512
+// fused head map: one 128-byte row per head-map pixel: [box napl*7 | cls napl | dir napl*2 | 0 pad]
+#define PP_HEAD_COLS 32
 
 // ----- voxel grid geometry (float64, as the reference's index math) -----
 struct VoxGeom {
@@ -42,6 +44,10 @@ struct LayerDesc {
     float* out;           // output base
     int ld_out;           // channels per output pixel row (row stride, floats)
     int co_off;           // channel offset inside the output row (concat placement)
+    // heads fused into a deconv's epilogue (head_mode 1: write partial + bias, 2: add partial)
+    int head_mode;
+    float* d_head_wt;     // [PP_HEAD_COLS][cout] slice of the head kernels, transposed
+    float* d_head_bias;   // [PP_HEAD_COLS]
     const char* name;
 };
 
@@ -84,18 +90,18 @@ int launch_pfn(const PfnParams& p, bool padded_source, hipStream_t s);  // retur
 void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, const int* cells, int64_t A,
                         float threshold, int* integ, uint8_t* mask, hipStream_t s);
 
+bool deconv_can_fuse_heads(const LayerDesc& L);
 std::string layer_kernel_name(const LayerDesc& L, int batch);  // template instantiation that runs L at this batch
-int launch_layer(const LayerDesc& L, int batch, float* d_box, float* d_cls, float* d_dir, int napl,
-                 hipStream_t s, int ablate = 0);  // returns 0 or PP_ERR_UNSUPPORTED
+int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s,
+                 int ablate = 0);  // returns 0 or PP_ERR_UNSUPPORTED
 
 struct PostParams {
     int batch;
     int64_t A;
     int pre_max, post_max;
     float score_thr, iou_thr;
-    const float* box;      // [batch][A][7]
-    const float* cls;      // [batch][A]
-    const float* dir;      // [batch][A][2]
+    const float* head;     // [batch][H'*W'][PP_HEAD_COLS] fused head map
+    int napl;              // anchors per location
     const uint8_t* mask;   // [batch][A]
     const float* anchors;  // [A][7]
     const float* calib;    // [batch][16]  rect @ Trv2c (float32)
