@@ -23,6 +23,7 @@
 
 #define PT 1024
 #define KMAX 128   // >= the reference's hard-coded top-100
+#define CCAP 12288 // candidate keys kept in LDS (96 KB); more candidates -> re-read the head map per pass
 
 __device__ __forceinline__ unsigned long long comp_key(float logit, unsigned a) {
     unsigned u = __float_as_uint(logit);
@@ -32,6 +33,8 @@ __device__ __forceinline__ unsigned long long comp_key(float logit, unsigned a) 
 
 __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     __shared__ int s_hist[256];
+    __shared__ unsigned long long s_ckey[CCAP];   // compacted candidate keys (order irrelevant: keys are unique)
+    __shared__ int s_ncand;
     __shared__ unsigned long long s_prefix;
     __shared__ int s_need, s_shift, s_done, s_cnt;
     __shared__ unsigned long long s_key[KMAX];
@@ -69,19 +72,38 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         return true;
     };
 
+    // ---- candidates -> LDS once (the head map is read a single time; the select passes run on LDS) ----
+    if (tid == 0) { s_prefix = 0ull; s_need = KTOP; s_shift = 56; s_done = 0; s_cnt = 0; s_ncand = 0; }
+    __syncthreads();
+    for (long long a = tid; a < A; a += PT) {
+        float lg;
+        if (!is_cand(a, lg)) continue;
+        const int pos = atomicAdd(&s_ncand, 1);
+        if (pos < CCAP) s_ckey[pos] = comp_key(lg, (unsigned)a);
+    }
+    __syncthreads();
+    const int ncand = s_ncand;
+    const bool in_lds = ncand <= CCAP;
+
     // ---- radix select of the KTOP largest composite keys (8 bits per pass, MSB first) ----
-    if (tid == 0) { s_prefix = 0ull; s_need = KTOP; s_shift = 56; s_done = 0; s_cnt = 0; }
     for (int pass = 0; pass < 8; ++pass) {
         if (tid < 256) s_hist[tid] = 0;
         __syncthreads();
         if (s_done) break;
         const int shift = 56 - 8 * pass;
         const unsigned long long prefix = s_prefix;
-        for (long long a = tid; a < A; a += PT) {
-            float lg;
-            if (!is_cand(a, lg)) continue;
-            const unsigned long long key = comp_key(lg, (unsigned)a);
-            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&s_hist[(int)((key >> shift) & 255ull)], 1);
+        if (in_lds) {
+            for (int i = tid; i < ncand; i += PT) {
+                const unsigned long long key = s_ckey[i];
+                if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&s_hist[(int)((key >> shift) & 255ull)], 1);
+            }
+        } else {
+            for (long long a = tid; a < A; a += PT) {
+                float lg;
+                if (!is_cand(a, lg)) continue;
+                const unsigned long long key = comp_key(lg, (unsigned)a);
+                if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&s_hist[(int)((key >> shift) & 255ull)], 1);
+            }
         }
         __syncthreads();
         if (tid == 0) {
@@ -107,13 +129,23 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     {
         const int shift = s_shift;
         const unsigned long long prefix = s_prefix;
-        for (long long a = tid; a < A; a += PT) {
-            float lg;
-            if (!is_cand(a, lg)) continue;
-            const unsigned long long key = comp_key(lg, (unsigned)a);
-            if ((key >> shift) >= prefix) {
-                const int pos = atomicAdd(&s_cnt, 1);
-                if (pos < KMAX) s_key[pos] = key;
+        if (in_lds) {
+            for (int i = tid; i < ncand; i += PT) {
+                const unsigned long long key = s_ckey[i];
+                if ((key >> shift) >= prefix) {
+                    const int pos = atomicAdd(&s_cnt, 1);
+                    if (pos < KMAX) s_key[pos] = key;
+                }
+            }
+        } else {
+            for (long long a = tid; a < A; a += PT) {
+                float lg;
+                if (!is_cand(a, lg)) continue;
+                const unsigned long long key = comp_key(lg, (unsigned)a);
+                if ((key >> shift) >= prefix) {
+                    const int pos = atomicAdd(&s_cnt, 1);
+                    if (pos < KMAX) s_key[pos] = key;
+                }
             }
         }
     }
