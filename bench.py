@@ -40,10 +40,11 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
 
-def layer_flops(d, batch):
+def layer_flops(d, batch, heads_fused=False):
     """Algorithmic FLOPs per launch of every backbone layer:
     depthwise 2*9*Cin + pointwise 2*Cin*Cout per output pixel; deconv 2*Cin*k*k*Cout per
-    input pixel; heads 2*384*(14+2+4) per pixel."""
+    input pixel; heads 2*384*(14+2+4) per pixel (credited to the deconv launches, branch by
+    branch, when the heads are fused into their epilogues)."""
     out = {}
     h, w, cin = d.ny, d.nx, d.pfn_filters
     for b in range(3):
@@ -56,7 +57,11 @@ def layer_flops(d, batch):
         k = d.upsample_strides[b]
         out[f"deconv{b + 1}"] = 2.0 * batch * h * w * cin * k * k * d.num_upsample_filters[b]
     n_head = d.num_anchor_per_loc * (7 + d.num_class + 2)
-    out["heads"] = 2.0 * batch * d.head_h * d.head_w * d.concat_channels * n_head
+    if heads_fused:
+        for b in range(3):
+            out[f"deconv{b + 1}"] += 2.0 * batch * d.head_h * d.head_w * d.num_upsample_filters[b] * n_head
+    else:
+        out["heads"] = 2.0 * batch * d.head_h * d.head_w * d.concat_channels * n_head
     return out
 
 
@@ -196,7 +201,8 @@ def main():
     kernel_ms = {k: v[0] / prof_steps for k, v in agg.items()}        # per step
     launches = {k: v[1] / prof_steps for k, v in agg.items()}
     dominant = max(kernel_ms, key=kernel_ms.get)
-    lf = layer_flops(d, B)
+    heads_fused = not any(t.endswith(":heads") for t in eng.layer_tags())
+    lf = layer_flops(d, B, heads_fused)
     sb = stage_bytes(d, B, N, float(im_np.mean()))
     if dominant.startswith("k_gemm"):
         flops_step = sum(lf[tag.split(":")[1]] for tag in per_layer if tag.startswith(dominant + ":"))

@@ -25,7 +25,7 @@ eng.load_weights(pp.weights.init_weights(eng.d, seed=7))
 frames = [pp.synth.d435i_cloud(i) if args.config == "A" else pp.synth.kitti_cloud(i) for i in range(B)]
 eng.detect(frames)   # fill the activation buffers with real data
 tags = eng.layer_tags()
-lf = layer_flops(eng.d, B)
+lf = layer_flops(eng.d, B, heads_fused=not any(t.endswith(':heads') for t in tags))
 sel = [int(v) for v in args.layers.split(",")] if args.layers else range(len(tags))
 abl = [int(v) for v in args.ablate.split(",")]
 tot = {a: 0.0 for a in abl}
