@@ -400,18 +400,24 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2 && NT == 128) ? 3 : 4
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (!(dbg & 2)) {
+                        // all 9 tap vectors of this chunk first (one LDS latency, overlapping the tail of the
+                        // global-load wait), then the FMAs
+                        float4 wv[9];
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(sDW + t * cin + ch);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                             for (int dx = 0; dx < 3; ++dx) {
-                                const float4 wv = *reinterpret_cast<const float4*>(sDW + (dy * 3 + dx) * cin + ch);
+                                const float4 w4 = wv[dy * 3 + dx];
 #pragma unroll
                                 for (int j = 0; j < PXT; ++j) {
                                     const float4 v = rin[dy * WW + j * S + dx];
-                                    o[j].x = fmaf(v.x, wv.x, o[j].x);
-                                    o[j].y = fmaf(v.y, wv.y, o[j].y);
-                                    o[j].z = fmaf(v.z, wv.z, o[j].z);
-                                    o[j].w = fmaf(v.w, wv.w, o[j].w);
+                                    o[j].x = fmaf(v.x, w4.x, o[j].x);
+                                    o[j].y = fmaf(v.y, w4.y, o[j].y);
+                                    o[j].z = fmaf(v.z, w4.z, o[j].z);
+                                    o[j].w = fmaf(v.w, w4.w, o[j].w);
                                 }
                             }
                     }
