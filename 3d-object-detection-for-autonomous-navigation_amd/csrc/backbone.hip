@@ -25,10 +25,23 @@
 // HBM in between.  Workgroup ids are remapped so that consecutive pixel tiles
 // (which share halo rows) land on the same XCD / L2.
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "pp_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte buffer load: address = SRD base + voffset (VGPR, bytes) + soffset (SGPR, bytes).  One VGPR
+// per address and no 64-bit vector address arithmetic (a plain pointer + varying uniform base made
+// the compiler rebuild 64-bit addresses for every load of every K-chunk).
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffffe, 0x00020000);
+}
 
 #define PX_TILE 128
 #define KC 32
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(256) void k_gemm_layer(GemmArgs a) {
 // channel rows with 16-byte stores (full 128-B lines).  Odd-width separable layers use
 // k_gemm_layer above.
 template <int NT, int MODE, int S, int PXB>
-__global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2 && NT == 128) ? 3 : 4) void k_gemm_ws(GemmArgs a) {
+__global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2) ? 3 : 4) void k_gemm_ws(GemmArgs a) {
     constexpr int NCW = PXB / 32;                    // consumer waves == producer waves
     constexpr int NPT = NCW * 64;                    // producer (and consumer) threads
     constexpr int KCH = (MODE == 0) ? 16 : 32;      // channels per K-chunk
@@ -321,8 +334,8 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2 && NT == 128) ? 3 : 4
         // pixel past the end of the last tile) simply loads from that header, so no value is ever
         // selected after the load (a select on the LOADED value would serialise the loads, and masking
         // at use costs 4 v_cndmask per element).
-        const char* const inb = reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4;
-        const char* const wtb = reinterpret_cast<const char*>(a.wt);
+        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
+        const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt);
         unsigned cbase;
         unsigned okmask = 0;                          // bit dy*WW+dx: that window element is inside the map
         if (MODE == 0) {
@@ -343,31 +356,41 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2 && NT == 128) ? 3 : 4
             if (pvalid && !(dbg & 8)) okmask = 1u;
         }
         const int rs4 = a.in_w * cin * 4, cin4 = cin * 4;   // row / pixel stride in bytes (uniform)
+        // per-thread byte offsets of the NLD window elements (incl. this lane's channel group), fixed for
+        // the whole K loop: a K-chunk only moves the UNIFORM base pointer, so issuing a chunk's loads
+        // costs no vector ALU work at all (the address is saddr + this VGPR)
+        unsigned aoff[NLD];
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            unsigned off_;   // out-of-map -> the zero header
+            if (MODE == 0) off_ = ((okmask >> e) & 1u) ? cbase + (unsigned)((e / WW - 1) * rs4 + (e % WW - 1) * cin4) : 0u;
+            else off_ = okmask ? cbase + (unsigned)(e * cin4) : 0u;
+            aoff[e] = off_ + (unsigned)(c4 * 16);
+        }
         float4 rin[NLD];
         float4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;   // weight prefetch (named scalars: an array ended up in scratch)
         rb0 = rb1 = rb2 = rb3 = rb4 = rb5 = rb6 = rb7 = make_float4(0.f, 0.f, 0.f, 0.f);
         static_assert(NB4 <= 8, "weight prefetch registers");
         float* const dA = sA + (PXT * q) * LSTR + c4 * 4;
+        unsigned boff[NB4 > 0 ? NB4 : 1];               // weight-tile byte offsets, fixed likewise
+#pragma unroll
+        for (int r = 0; r < NB4; ++r) {
+            const int e_ = pt + NPT * r;
+            boff[r] = (unsigned)(((n0 + e_ / G) * cin + (e_ % G) * 4) * 4);
+        }
 
-        // (a macro, not a lambda: by-reference captures of rin / rb kept those arrays in scratch memory)
+        // (macros, not lambdas: by-reference captures of rin / rb kept those arrays in scratch memory)
 #define WS_LOAD_CHUNK(KCIDX)                                                                             \
         {                                                                                                \
-            const unsigned chb_ = (unsigned)((KCIDX) * KCH + c4 * 4) * 4u;                               \
-            _Pragma("unroll") for (int e = 0; e < NLD; ++e) {                                            \
-                unsigned off_;   /* out-of-map -> the zero header (offset = channel offset only) */     \
-                if (MODE == 0) off_ = ((okmask >> e) & 1u) ? cbase + (unsigned)((e / WW - 1) * rs4 + (e % WW - 1) * cin4) : 0u; \
-                else off_ = okmask ? cbase + (unsigned)(e * cin4) : 0u;                                  \
-                rin[e] = *reinterpret_cast<const float4*>(inb + (off_ + chb_));                          \
-            }                                                                                            \
-            WS_LOAD_B(0, rb0, KCIDX) WS_LOAD_B(1, rb1, KCIDX) WS_LOAD_B(2, rb2, KCIDX) WS_LOAD_B(3, rb3, KCIDX) \
-            WS_LOAD_B(4, rb4, KCIDX) WS_LOAD_B(5, rb5, KCIDX) WS_LOAD_B(6, rb6, KCIDX) WS_LOAD_B(7, rb7, KCIDX) \
+            const unsigned so_ = (unsigned)(KCIDX) * (KCH * 4);   /* uniform: scalar offset operand */  \
+            _Pragma("unroll") for (int e = 0; e < NLD; ++e) rin[e] = buf_load16(rs_in, aoff[e], so_);    \
+            WS_LOAD_B(0, rb0) WS_LOAD_B(1, rb1) WS_LOAD_B(2, rb2) WS_LOAD_B(3, rb3)                      \
+            WS_LOAD_B(4, rb4) WS_LOAD_B(5, rb5) WS_LOAD_B(6, rb6) WS_LOAD_B(7, rb7)                      \
         }
-#define WS_LOAD_B(R, REG, KCIDX)                                                                         \
+#define WS_LOAD_B(R, REG)                                                                                \
         if (NB4 > (R)) {                                                                                 \
-            const int e_ = pt + NPT * (R);                                                               \
-            if ((NT * G) % NPT == 0 || e_ < NT * G)                                                      \
-                REG = *reinterpret_cast<const float4*>(                                                  \
-                    wtb + (unsigned)(((n0 + e_ / G) * cin + (KCIDX) * KCH + (e_ % G) * 4) * 4));         \
+            if ((NT * G) % NPT == 0 || pt + NPT * (R) < NT * G)                                          \
+                REG = buf_load16(rs_wt, boff[(R) < NB4 ? (R) : 0], so_);                                 \
         }
 #define WS_STORE_B(R, REG)                                                                               \
         if (NB4 > (R)) {                                                                                 \
@@ -382,14 +405,21 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2 && NT == 128) ? 3 : 4
             WS_LOAD_CHUNK(0)
         }
         __syncthreads();   // (A) depthwise taps / s_opix visible; chunk-0 loads are already in flight
+#ifdef PP_KERNEL_STAMPS   // diagnostic build (tools/layer_bench.py --ablate 64): in-kernel phase stamps
         const bool stamp = (dbg & 64) && a.stamps != nullptr && blockIdx.x < 64 && blockIdx.y == 0 && pt == 0;
         long long* st = a.stamps ? a.stamps + ((size_t)blockIdx.x * 2 + 1) * 40 * 4 : nullptr;
+#else
+        constexpr bool stamp = false;
+        long long* st = nullptr;
+#endif
         for (int s = -1; s < nchunks; ++s) {
             if (stamp && s + 1 < 40) st[(s + 1) * 4 + 0] = clock64();
+#ifdef PP_KERNEL_STAMPS
             if ((dbg & 64) && a.stamps != nullptr && blockIdx.x < 64 && blockIdx.y == 0 && wave == NCW) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic build only: isolate the load wait
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // isolate the load wait
                 if (stamp && s + 1 < 40) st[(s + 1) * 4 + 1] = clock64();
             }
+#endif
             if (s + 1 < nchunks) {
                 // ---- stage chunk s+1 (registers -> LDS buffer (s+1)&1) ----
                 const int kc = s + 1, buf = kc & 1;
@@ -455,8 +485,13 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2 && NT == 128) ? 3 : 4
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     const int h = lane >> 5, r32 = lane & 31;
     __syncthreads();   // (A)
+#ifdef PP_KERNEL_STAMPS
     const bool stamp = (dbg & 64) && a.stamps != nullptr && blockIdx.x < 64 && blockIdx.y == 0 && tid == 0;
     long long* st = a.stamps ? a.stamps + ((size_t)blockIdx.x * 2 + 0) * 40 * 4 : nullptr;
+#else
+    constexpr bool stamp = false;
+    long long* st = nullptr;
+#endif
     if (stamp) st[0] = clock64();
     __syncthreads();   // chunk 0 staged
     if (stamp) st[3] = clock64();
@@ -566,6 +601,7 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2 && NT == 128) ? 3 : 4
     }
     if (stamp) st[39 * 4 + 1] = clock64();
 }
+
 
 template <int NT, int MODE>
 static void launch_t(const GemmArgs& a, int n_total, hipStream_t s) {
