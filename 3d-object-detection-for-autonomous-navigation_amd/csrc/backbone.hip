@@ -503,17 +503,35 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2) ? 3 : 4) void k_gemm
 #pragma unroll
         for (int q = 0; q < KQ; ++q) a4[q] = *reinterpret_cast<const float4*>(cA + q * 4);
         if (!(dbg & 1)) {
+            if constexpr (NTILES * KQ <= 8) {
+                // all B fragments of the chunk first (one LDS latency), then the MFMAs back to back
+                float4 bq[NTILES][KQ];
 #pragma unroll
-            for (int n = 0; n < NTILES; ++n) {
-                float4 b4[KQ];
+                for (int n = 0; n < NTILES; ++n)
 #pragma unroll
-                for (int q = 0; q < KQ; ++q) b4[q] = *reinterpret_cast<const float4*>(cB + n * 32 * LSTR + q * 4);
+                    for (int q = 0; q < KQ; ++q) bq[n][q] = *reinterpret_cast<const float4*>(cB + n * 32 * LSTR + q * 4);
 #pragma unroll
-                for (int q = 0; q < KQ; ++q) {
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].x, b4[q].x, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].y, b4[q].y, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].z, b4[q].z, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].w, b4[q].w, acc[n], 0, 0, 0);
+                for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].x, bq[n][q].x, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].y, bq[n][q].y, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].z, bq[n][q].z, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].w, bq[n][q].w, acc[n], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NTILES; ++n) {
+                    float4 b4[KQ];
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q) b4[q] = *reinterpret_cast<const float4*>(cB + n * 32 * LSTR + q * 4);
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].x, b4[q].x, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].y, b4[q].y, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].z, b4[q].z, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].w, b4[q].w, acc[n], 0, 0, 0);
+                    }
                 }
             }
         }
