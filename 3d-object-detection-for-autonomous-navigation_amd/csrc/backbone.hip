@@ -44,6 +44,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
 }
 
 #define PX_TILE 128
+
+int g_num_cus = 256;   // set by pp_create from the device properties (persistent launches)
 #define KC 32
 #define LDS_STRIDE 36
 
@@ -621,6 +623,271 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2) ? 3 : 4) void k_gemm
 }
 
 
+// 4 x 4 transpose inside each quad of lanes (registers x lanes), two DPP butterfly stages: afterwards
+// lane (quad position i) holds, in r0..r3, what the quad's lanes 0..3 held in their register i.
+__device__ __forceinline__ float dpp_quad(float v, const int ctrl_xor1) {
+    const int x = __float_as_int(v);
+    return __int_as_float(ctrl_xor1 ? __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true)
+                                    : __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true));
+}
+#define QUAD_XCH(A, B, BIT, XOR1)                          \
+    {                                                      \
+        const float t_ = (BIT) ? (A) : (B);                \
+        const float u_ = dpp_quad(t_, XOR1);               \
+        (A) = (BIT) ? u_ : (A);                            \
+        (B) = (BIT) ? (B) : u_;                            \
+    }
+__device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2, float& r3, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    QUAD_XCH(r0, r1, b0, 1)
+    QUAD_XCH(r2, r3, b0, 1)
+    QUAD_XCH(r0, r2, b1, 0)
+    QUAD_XCH(r1, r3, b1, 0)
+}
+
+// ---------------------------------------------------------------------------------------
+// Uniform-wave separable layer (every wave prepares AND multiplies).
+//
+// A 4-wave workgroup owns 128 output pixels x NT channels; wave w owns pixels 32w..32w+31 for the
+// whole K loop.  Per 16-channel K-chunk a wave (1) turns its prefetched 3 x (S+3) input windows
+// into the depthwise result of ITS OWN 32 pixels, written to a wave-private LDS A tile (no
+// workgroup synchronisation: a wave's LDS operations execute in order), (2) stages its share of
+// the weight chunk (the only shared operand), (3) issues the global loads of the chunk after
+// next, (4) runs the 8 x NT/32 MFMAs of the current chunk; one workgroup barrier per chunk (for
+// the weight tile).  Compared with the producer/consumer kernel above no wave slot is spent on
+// waves that mostly wait for memory: with 3 workgroups per CU every SIMD holds three waves that
+// all feed the matrix pipe, each hiding its own load latency behind the other two's MFMAs, and
+// the scheduling grain is one wave per 32 pixels (tile quantisation costs less).  The epilogue
+// stores straight from the accumulators: for a fixed accumulator register the 32 lanes of a
+// half-wave hold 32 consecutive channels of one pixel = one full 128-byte line.
+template <int NT, int S, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
+    constexpr int KCH = 16, LSTR = KCH + 4, G = 4;
+    constexpr int WW = S + 3;                        // input window width of 2 adjacent output pixels
+    constexpr int NLD = 3 * WW;
+    constexpr int SAW = 32 * LSTR;                   // one wave-private A buffer (floats)
+    constexpr int SB = NT * LSTR;
+    constexpr int NB4 = (NT * G + 255) / 256;        // weight float4 per thread per chunk
+    constexpr int NTILES = NT / 32;
+    constexpr int KQ = KCH / 8;
+    __shared__ __attribute__((aligned(16))) float smem[8 * SAW + 2 * SB + 9 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.dbg & 128) return;   // tuning aid: launch + dispatch cost only
+#ifdef PP_KERNEL_STAMPS   // diagnostic build: wall-clock phase stamps of every workgroup (wave 0)
+    long long* ust = ((a.dbg & 64) && a.stamps && tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096)
+                         ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+    if (ust) {
+        ust[0] = wall_clock64();
+        ust[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+        ust[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+#define U_STAMP(i) { if (ust) ust[i] = wall_clock64(); }
+#else
+#define U_STAMP(i) {}
+#endif
+    float* const sAw = smem + wave * 2 * SAW;
+    float* const sB = smem + 8 * SAW;
+    float* const sDW = smem + 8 * SAW + 2 * SB;
+
+    // ---- this workgroup's tiles: XCD x (= blockIdx.x & 7, the dispatch order) owns the contiguous tile
+    // range [x * ntiles / 8, (x + 1) * ntiles / 8); its workgroups walk that range together, so the halo
+    // rows two neighbouring tiles share are served by one L2 ----
+    const int xcd = blockIdx.x & 7, gl = blockIdx.x >> 3, GL = gridDim.x >> 3;
+    const int tbase = (int)(((long long)xcd * ntiles) >> 3), tend = (int)(((long long)(xcd + 1) * ntiles) >> 3);
+    const int first = tbase + gl;
+    if (first >= tend) return;                         // uniform for the workgroup
+    const int ntl = (tend - first + GL - 1) / GL;      // tiles of this workgroup
+    const int n0 = blockIdx.y * NT;
+    const int cin = a.cin;
+    const int nchunks = cin / KCH;
+    const int dbg = a.dbg;
+    const int total = ntl * nchunks;                   // K-chunks in this workgroup's stream
+
+    for (int e = tid; e < 9 * cin / 4; e += 256)
+        reinterpret_cast<float4*>(sDW)[e] = reinterpret_cast<const float4*>(a.dw)[e];
+
+    // ---- staging role: lane (q, c4) owns output pixels pw + 2q, +1 and channels 4*c4..+3 of a chunk ----
+    const int c4 = lane & 3, q = lane >> 2;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt);
+    const int hw = a.px_h * a.px_w;
+    const int rs4 = a.in_w * cin * 4, cin4 = cin * 4;
+    unsigned aoff[NLD];
+    // byte offsets of the 3 x WW window of this lane's pixel pair in tile `tile` (out-of-map -> zero header)
+#define U_TILE_OFFSETS(TILE)                                                                             \
+    {                                                                                                    \
+        const int pix0_ = (TILE) * 128 + wave * 32 + 2 * q;                                              \
+        const bool pvalid_ = pix0_ < a.M;                                                                \
+        const int pc_ = pvalid_ ? pix0_ : 0;                                                             \
+        const int b_ = pc_ / hw;                                                                         \
+        const int rem_ = pc_ - b_ * hw;                                                                  \
+        const int y_ = rem_ / a.px_w, x0_ = rem_ - y_ * a.px_w;                                          \
+        const int yi_ = y_ * S - 1, xi_ = x0_ * S - 1;                                                   \
+        const unsigned cbase_ =                                                                          \
+            (unsigned)(((b_ * a.in_h + y_ * S) * a.in_w + x0_ * S) * cin) * 4u + PP_ZPAD_FLOATS * 4u;    \
+        _Pragma("unroll") for (int e = 0; e < NLD; ++e) {                                                \
+            const int dy_ = e / WW, dx_ = e % WW;                                                        \
+            const bool ok_ = pvalid_ && yi_ + dy_ >= 0 && yi_ + dy_ < a.in_h && xi_ + dx_ >= 0 &&        \
+                             xi_ + dx_ < a.in_w && !(dbg & 8);                                           \
+            aoff[e] = (ok_ ? cbase_ + (unsigned)((dy_ - 1) * rs4 + (dx_ - 1) * cin4) : 0u) +             \
+                      (unsigned)(c4 * 16);                                                               \
+        }                                                                                                \
+    }
+    unsigned boff[NB4];
+#pragma unroll
+    for (int r = 0; r < NB4; ++r) {
+        const int e_ = tid + 256 * r;
+        boff[r] = (unsigned)(((n0 + (e_ / G) % NT) * cin + (e_ % G) * 4) * 4);
+    }
+    float4 rin[NLD];
+    float4 rb0, rb1;
+    rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_assert(NB4 <= 2, "weight prefetch registers");
+#define U_LOAD_CHUNK(KCIDX)                                                                              \
+    {                                                                                                    \
+        const unsigned so_ = (unsigned)(KCIDX) * (KCH * 4);                                              \
+        _Pragma("unroll") for (int e = 0; e < NLD; ++e) rin[e] = buf_load16(rs_in, aoff[e], so_);        \
+        if ((NT * G) % 256 == 0 || tid < NT * G) rb0 = buf_load16(rs_wt, boff[0], so_);                  \
+        if (NB4 > 1) rb1 = buf_load16(rs_wt, boff[NB4 - 1], so_);                                        \
+    }
+    // three cursors walk the stream of (tile, chunk) positions: loads are issued two positions ahead of
+    // the MFMAs, staging runs one ahead
+    int ld_tile = first, ld_kc = 0;      // next position whose loads get issued
+    int st_kc = 0;                       // chunk index of the next position to stage
+    int mm_tile = first, mm_kc = 0;      // position the MFMAs work on
+    U_TILE_OFFSETS(ld_tile)
+    U_LOAD_CHUNK(0)
+    ld_kc = 1;                           // nchunks >= 2 (cin >= 32, checked by the launcher)
+
+    f32x16 acc[NTILES];
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const int h = lane >> 5, r32 = lane & 31;
+    __syncthreads();   // depthwise taps visible
+    U_STAMP(1)
+
+    for (int i = -1; i < total; ++i) {
+        if (i == 0) U_STAMP(2)
+#ifdef PP_KERNEL_STAMPS
+        if (ust && blockIdx.x < 64 && i + 1 < 64) a.stamps[4096 * 8 + blockIdx.x * 64 + i + 1] = wall_clock64();
+#endif
+        bool tile_done = false;
+        if (i >= 0) {
+            // ---- MFMAs of position i out of buffer i & 1 ----
+            if (!(dbg & 1)) {
+                const float* cA = sAw + (i & 1) * SAW + r32 * LSTR + h * (KCH / 2);
+                const float* cB = sB + (i & 1) * SB + r32 * LSTR + h * (KCH / 2);
+                float4 a4[KQ];
+#pragma unroll
+                for (int qq = 0; qq < KQ; ++qq) a4[qq] = *reinterpret_cast<const float4*>(cA + qq * 4);
+#pragma unroll
+                for (int n = 0; n < NTILES; ++n) {
+                    float4 b4[KQ];
+#pragma unroll
+                    for (int qq = 0; qq < KQ; ++qq) b4[qq] = *reinterpret_cast<const float4*>(cB + n * 32 * LSTR + qq * 4);
+#pragma unroll
+                    for (int qq = 0; qq < KQ; ++qq) {
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].x, b4[qq].x, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].y, b4[qq].y, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].z, b4[qq].z, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].w, b4[qq].w, acc[n], 0, 0, 0);
+                    }
+                }
+            }
+            tile_done = (++mm_kc == nchunks);
+        }
+        if (i + 1 < total) {
+            // ---- stage position i+1: depthwise of this wave's pixels -> private A tile; weight share -> sB ----
+            const int buf = (i + 1) & 1;
+            float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
+            if (!(dbg & 2)) {
+                const float* tw = sDW + st_kc * KCH + c4 * 4;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(tw + (dy * 3 + dx) * cin);
+                        const float4 v0 = rin[dy * WW + dx], v1 = rin[dy * WW + S + dx];
+                        o0.x = fmaf(v0.x, w4.x, o0.x); o0.y = fmaf(v0.y, w4.y, o0.y);
+                        o0.z = fmaf(v0.z, w4.z, o0.z); o0.w = fmaf(v0.w, w4.w, o0.w);
+                        o1.x = fmaf(v1.x, w4.x, o1.x); o1.y = fmaf(v1.y, w4.y, o1.y);
+                        o1.z = fmaf(v1.z, w4.z, o1.z); o1.w = fmaf(v1.w, w4.w, o1.w);
+                    }
+            }
+            float* dA = sAw + buf * SAW + (2 * q) * LSTR + c4 * 4;
+            *reinterpret_cast<float4*>(dA) = o0;
+            *reinterpret_cast<float4*>(dA + LSTR) = o1;
+            if ((NT * G) % 256 == 0 || tid < NT * G)
+                *reinterpret_cast<float4*>(sB + buf * SB + (tid / G) * LSTR + (tid % G) * 4) = rb0;
+            if (NB4 > 1)
+                *reinterpret_cast<float4*>(sB + buf * SB + ((tid + 256) / G) * LSTR + (tid % G) * 4) = rb1;
+            if (++st_kc == nchunks) st_kc = 0;
+            if (i + 2 < total) {
+                if (ld_kc == 0) U_TILE_OFFSETS(ld_tile)
+                U_LOAD_CHUNK(ld_kc)
+                if (++ld_kc == nchunks) { ld_kc = 0; ld_tile += GL; }
+            }
+        }
+        if (tile_done) {
+            // ---- tile finished: bias + ReLU, then a 4 x 4 register/lane transpose inside each lane quad
+            // turns "lane = channel, register = pixel row" into "lane holds 4 consecutive channels of one
+            // pixel": 16-byte stores, 8 full 128-byte lines per instruction (few, large stores: the store
+            // path is bound by requests in flight, not bytes).  Issued AFTER this iteration's prefetch
+            // loads: the memory counter retires in issue order, so the next iteration's wait for those
+            // loads does not also wait for the stores' acknowledgements; the stores drain while the next
+            // tile's chunks are multiplied. ----
+            const int pw = mm_tile * 128 + wave * 32;
+            if (!(dbg & 4) && pw < a.M) {
+                const int qi = lane & 3, qj = r32 >> 2;
+                float* dst = a.out + (size_t)(pw + 4 * h + qi) * a.ld_out + a.co_off + n0 + qj * 4;
+                const bool full = pw + 32 <= a.M;             // wave-uniform
+#pragma unroll
+                for (int n = 0; n < NTILES; ++n) {
+                    const float bvn = a.bias[n0 + n * 32 + r32];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);
+                        float x2 = fmaxf(acc[n][4 * g + 2] + bvn, 0.f), x3 = fmaxf(acc[n][4 * g + 3] + bvn, 0.f);
+                        quad_transpose4(x0, x1, x2, x3, lane);
+                        if (full || pw + 8 * g + 4 * h + qi < a.M)
+                            *reinterpret_cast<float4*>(dst + (size_t)(8 * g) * a.ld_out + n * 32) =
+                                make_float4(x0, x1, x2, x3);
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+            mm_kc = 0;
+            mm_tile += GL;
+        }
+        __syncthreads();
+    }
+#undef U_LOAD_CHUNK
+#undef U_TILE_OFFSETS
+    U_STAMP(3)
+#ifdef PP_KERNEL_STAMPS
+    if (a.dbg & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    U_STAMP(4)
+#endif
+}
+
+// persistent launch: WPS workgroups per CU (one wave per SIMD each), a multiple of 8 so that every XCD
+// gets the same number
+template <int NT, int S, int WPS>
+static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
+    const int ntiles = (a.M + 127) / 128;
+    const int ny = n_total / NT;
+    int slots = (g_num_cus * WPS) / ny;
+    int gx = ntiles < slots ? ntiles : slots;
+    gx = (gx + 7) & ~7;
+    dim3 grid((unsigned)gx, ny);
+    hipLaunchKernelGGL((k_sep_u<NT, S, WPS>), grid, dim3(256), 0, s, a, ntiles);
+}
+
 template <int NT, int MODE>
 static void launch_t(const GemmArgs& a, int n_total, hipStream_t s) {
     const unsigned mt = (unsigned)((a.M + PX_TILE - 1) / PX_TILE);
@@ -648,6 +915,31 @@ static void launch_ws(const GemmArgs& a, int n_total, hipStream_t s) {
     }
 }
 
+// separable layers: uniform-wave kernel (k_sep_u) or the producer/consumer kernel (k_gemm_ws).
+// k_sep_u is the default; PP_SEP_KERNEL=ws selects the other; pp_bench_layer's ablation bits 16 / 32
+// force u / ws.
+static bool sep_uniform(int ablate) {
+    static int dflt = -1;
+    if (dflt < 0) {
+        const char* e = getenv("PP_SEP_KERNEL");
+        dflt = (e && e[0] == 'w') ? 0 : 1;
+    }
+    if (ablate & 16) return true;
+    if (ablate & 32) return false;
+    return dflt == 1;
+}
+
+// channel-tile width of the uniform-wave kernel: the widest that divides cout, narrowed to 64 when
+// the layer would otherwise put fewer than ~2.5 waves on a SIMD (small maps: a wave per 32 pixels x NT
+// channels is the scheduling grain; the depthwise is recomputed per channel tile, which the idle
+// vector pipe absorbs)
+static int sep_u_nt(const LayerDesc& L, int batch) {
+    if (L.cout % 64 != 0) return 32;
+    if (L.cout % 128 != 0) return 64;
+    const long long waves128 = ((long long)batch * L.out_h * L.out_w + 31) / 32 * (L.cout / 128);
+    return (waves128 * 2 < 5ll * g_num_cus * 4) ? 64 : 128;
+}
+
 long long* g_stamps = nullptr;   // tuning aid: device buffer for in-kernel stamps (pp_bench_layer, ablate & 64)
 
 // which kernel runs layer L (shared by the launcher and the profiler tags)
@@ -673,7 +965,11 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
     const int nt = (L.kind == LAYER_HEAD) ? 32 : (L.cout % 128 == 0 ? 128 : (L.cout % 64 == 0 ? 64 : 32));
     const int mode = (L.kind == LAYER_SEP) ? 0 : 1;
     char buf[64];
-    if (use_ws(L)) {
+    if (L.kind == LAYER_SEP && use_ws(L) && sep_uniform(0)) {
+        const int unt = sep_u_nt(L, batch);
+        const int wps = (L.stride == 1) ? (unt == 128 ? 3 : 4) : (unt == 128 ? 2 : (unt == 64 ? 3 : 4));
+        snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d>", unt, L.stride, wps);
+    } else if (use_ws(L)) {
         const int pxb = ws_small_tile(layer_rows(L, batch), L.n_total, nt) ? 64 : 128;
         snprintf(buf, sizeof(buf), "k_gemm_ws<%d,%d,%d,%d>", nt, mode, mode == 0 ? L.stride : 1, pxb);
     } else {
@@ -702,7 +998,18 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
         a.px_h = L.out_h; a.px_w = L.out_w; a.epi = 0;
         a.M = batch * L.out_h * L.out_w;
         if (L.cout % 32 != 0) return PP_ERR_UNSUPPORTED;
-        if (use_ws(L)) {
+        if (use_ws(L) && sep_uniform(ablate)) {
+            const int nt = sep_u_nt(L, batch);
+            if (L.stride == 1) {
+                if (nt == 128) launch_u<128, 1, 3>(a, L.n_total, s);
+                else if (nt == 64) launch_u<64, 1, 4>(a, L.n_total, s);
+                else launch_u<32, 1, 4>(a, L.n_total, s);
+            } else {
+                if (nt == 128) launch_u<128, 2, 2>(a, L.n_total, s);
+                else if (nt == 64) launch_u<64, 2, 3>(a, L.n_total, s);
+                else launch_u<32, 2, 4>(a, L.n_total, s);
+            }
+        } else if (use_ws(L)) {
             if (L.stride == 1) {
                 if (L.cout % 128 == 0) launch_ws<128, 0, 1>(a, L.n_total, s);
                 else if (L.cout % 64 == 0) launch_ws<64, 0, 1>(a, L.n_total, s);

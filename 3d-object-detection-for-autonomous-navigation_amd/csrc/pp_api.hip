@@ -11,6 +11,8 @@
 
 #include "pp_common.h"
 
+extern int g_num_cus;   // backbone.hip: CU count for persistent launches
+
 namespace {
 
 std::string g_create_error;
@@ -384,6 +386,11 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
         fail(nullptr, PP_ERR_HIP, "pp_create: %s", hipGetErrorString(st));
         delete e;
         return PP_ERR_HIP;
+    }
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
+            g_num_cus = ncu;
     }
     for (int j = 0; j < 3; ++j) {
         e->geom.lo[j] = cfg->pc_range[j];
@@ -937,7 +944,7 @@ int pp_bench_layer(pp_handle e, int32_t layer, int32_t batch, int32_t reps, int3
     (void)hipSetDevice(e->device);
     int st = check_batch(e, batch); if (st) return st;
     const LayerDesc& L = e->layers[layer];
-    if ((ablate & 64) && !g_stamps) HIPCHK(e, hipMalloc((void**)&g_stamps, 64 * 2 * 40 * 4 * sizeof(long long)));
+    if ((ablate & 64) && !g_stamps) HIPCHK(e, hipMalloc((void**)&g_stamps, (4096 * 8 + 64 * 64) * sizeof(long long)));
     for (int i = 0; i < 2; ++i)
         if ((st = launch_layer(L, batch, e->d_head, e->stream, ablate))) return fail(e, st, "pp_bench_layer: unsupported layer");
     HIPCHK(e, hipEventRecord(e->t0, e->stream));
@@ -949,12 +956,15 @@ int pp_bench_layer(pp_handle e, int32_t layer, int32_t batch, int32_t reps, int3
     HIPCHK(e, hipEventElapsedTime(&ms, e->t0, e->t1));
     *avg_ms = ms / reps;
     if (ablate & 64) {   // in-kernel stamps of one extra launch -> stderr (tuning aid)
-        const size_t n = 64 * 2 * 40 * 4;
+        const size_t n = 4096 * 8 + 64 * 64;
         std::vector<long long> hs(n, 0);
         HIPCHK(e, hipMemsetAsync(g_stamps, 0, n * sizeof(long long), e->stream));
         launch_layer(L, batch, e->d_head, e->stream, ablate);
         HIPCHK(e, hipMemcpyAsync(hs.data(), g_stamps, n * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (const char* path = getenv("PP_STAMPS_OUT")) {   // raw dump for offline analysis
+            if (FILE* f = fopen(path, "wb")) { fwrite(hs.data(), sizeof(long long), n, f); fclose(f); }
+        }
         for (int blk : {0, 1, 8, 63}) {
             for (int role = 0; role < 2; ++role) {
                 const long long* st = hs.data() + ((size_t)blk * 2 + role) * 160;

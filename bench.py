@@ -204,7 +204,7 @@ def main():
     heads_fused = not any(t.endswith(":heads") for t in eng.layer_tags())
     lf = layer_flops(d, B, heads_fused)
     sb = stage_bytes(d, B, N, float(im_np.mean()))
-    if dominant.startswith("k_gemm"):
+    if dominant.startswith(("k_gemm", "k_sep_u")):
         flops_step = sum(lf[tag.split(":")[1]] for tag in per_layer if tag.startswith(dominant + ":"))
         per_launch = flops_step / launches[dominant]
         avg_ms = kernel_ms[dominant] / launches[dominant]
