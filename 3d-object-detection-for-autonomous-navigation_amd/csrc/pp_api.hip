@@ -983,6 +983,75 @@ int pp_bench_layer(pp_handle e, int32_t layer, int32_t batch, int32_t reps, int3
     return PP_OK;
 }
 
+// ---- AP-evaluator overlaps (stateless: host buffers in, host buffers out) ----
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+int riou_common(int device, const float* boxes, int64_t n, const float* qboxes, int64_t k, int32_t criterion,
+                DevBuf& d_out, const char* who) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, PP_ERR_HIP, "%s: no HIP device available (this library has no CPU fallback)", who);
+    if (device < 0 || device >= ndev) return fail(nullptr, PP_ERR_ARG, "%s: device %d not in [0,%d)", who, device, ndev);
+    if (n < 0 || k < 0 || (n > 0 && !boxes) || (k > 0 && !qboxes)) return fail(nullptr, PP_ERR_ARG, "%s: bad argument", who);
+    if (criterion < -1 || criterion > 2) return fail(nullptr, PP_ERR_ARG, "%s: criterion %d not in {-1,0,1,2}", who, criterion);
+    if (n > 200000) return fail(nullptr, PP_ERR_ARG, "%s: at most 200000 boxes per call (got %lld)", who, (long long)n);
+#define RCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(nullptr, PP_ERR_HIP, "%s: %s", who, hipGetErrorString(e_)); } while (0)
+    RCHK(hipSetDevice(device));
+    DevBuf d_b, d_q, d_bc, d_qc;
+    RCHK(d_b.alloc(sizeof(float) * 5 * n)); RCHK(d_q.alloc(sizeof(float) * 5 * k));
+    RCHK(d_bc.alloc(sizeof(float) * 9 * n)); RCHK(d_qc.alloc(sizeof(float) * 9 * k));
+    RCHK(d_out.alloc(sizeof(float) * n * k));
+    if (n == 0 || k == 0) return PP_OK;
+    RCHK(hipMemcpy(d_b.p, boxes, sizeof(float) * 5 * n, hipMemcpyHostToDevice));
+    RCHK(hipMemcpy(d_q.p, qboxes, sizeof(float) * 5 * k, hipMemcpyHostToDevice));
+    launch_riou_corners((const float*)d_b.p, n, (float*)d_bc.p, nullptr);
+    launch_riou_corners((const float*)d_q.p, k, (float*)d_qc.p, nullptr);
+    launch_riou_pairs((const float*)d_bc.p, n, (const float*)d_qc.p, k, criterion, (float*)d_out.p, nullptr);
+    RCHK(hipGetLastError());
+    return PP_OK;
+}
+}  // namespace
+
+int pp_rotate_iou_eval(int device, const float* boxes, int64_t n, const float* query_boxes, int64_t k,
+                       int32_t criterion, float* out) {
+    DevBuf d_out;
+    int st = riou_common(device, boxes, n, query_boxes, k, criterion, d_out, "pp_rotate_iou_eval");
+    if (st || n == 0 || k == 0) return st;
+    if (!out) return fail(nullptr, PP_ERR_ARG, "pp_rotate_iou_eval: out is null");
+    const char* who = "pp_rotate_iou_eval";
+    RCHK(hipMemcpy(out, d_out.p, sizeof(float) * n * k, hipMemcpyDeviceToHost));
+    return PP_OK;
+}
+
+int pp_d3_box_overlap(int device, const double* boxes, int64_t n, const double* query_boxes, int64_t k,
+                      int32_t criterion, double* out) {
+    const char* who = "pp_d3_box_overlap";
+    if (n < 0 || k < 0 || (n > 0 && !boxes) || (k > 0 && !query_boxes)) return fail(nullptr, PP_ERR_ARG, "%s: bad argument", who);
+    // BEV rectangles [x, z, l, w, ry] in float32, raw intersection area (criterion 2), like eval.py:160-161
+    std::vector<float> b5((size_t)n * 5), q5((size_t)k * 5);
+    const int sel[5] = {0, 2, 3, 5, 6};
+    for (int64_t i = 0; i < n; ++i) for (int j = 0; j < 5; ++j) b5[i * 5 + j] = (float)boxes[i * 7 + sel[j]];
+    for (int64_t i = 0; i < k; ++i) for (int j = 0; j < 5; ++j) q5[i * 5 + j] = (float)query_boxes[i * 7 + sel[j]];
+    DevBuf d_rinc;
+    int st = riou_common(device, b5.data(), n, q5.data(), k, 2, d_rinc, who);
+    if (st || n == 0 || k == 0) return st;
+    if (!out) return fail(nullptr, PP_ERR_ARG, "%s: out is null", who);
+    if (criterion < -1 || criterion > 2) return fail(nullptr, PP_ERR_ARG, "%s: criterion %d not in {-1,0,1,2}", who, criterion);
+    DevBuf d_b, d_q, d_o;
+    RCHK(d_b.alloc(sizeof(double) * 7 * n)); RCHK(d_q.alloc(sizeof(double) * 7 * k)); RCHK(d_o.alloc(sizeof(double) * n * k));
+    RCHK(hipMemcpy(d_b.p, boxes, sizeof(double) * 7 * n, hipMemcpyHostToDevice));
+    RCHK(hipMemcpy(d_q.p, query_boxes, sizeof(double) * 7 * k, hipMemcpyHostToDevice));
+    launch_d3_finish((const double*)d_b.p, n, (const double*)d_q.p, k, criterion, (const float*)d_rinc.p, (double*)d_o.p, nullptr);
+    RCHK(hipGetLastError());
+    RCHK(hipMemcpy(out, d_o.p, sizeof(double) * n * k, hipMemcpyDeviceToHost));
+#undef RCHK
+    return PP_OK;
+}
+
 int pp_device_info(pp_handle e, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes) {
     if (!e) return PP_ERR_ARG;
     hipDeviceProp_t prop;

@@ -109,3 +109,9 @@ struct PostParams {
     int* n_dets;           // [batch]
 };
 void launch_postprocess(const PostParams& p, hipStream_t s);
+
+// rotate_iou.hip: rotated-box overlaps of the AP evaluator
+void launch_riou_corners(const float* boxes, int64_t n, float* corners, hipStream_t s);
+void launch_riou_pairs(const float* bc, int64_t N, const float* qc, int64_t K, int criterion, float* out, hipStream_t s);
+void launch_d3_finish(const double* boxes, int64_t N, const double* qboxes, int64_t K, int criterion,
+                      const float* rinc, double* out, hipStream_t s);

@@ -192,6 +192,21 @@ int pp_bench_layer(pp_handle h, int32_t layer, int32_t batch, int32_t reps, int3
 int pp_layer_count(pp_handle h, int32_t* count);
 const char* pp_layer_tag(pp_handle h, int32_t layer);
 
+/* ---- AP-evaluator overlaps ------------------ */
+
+/* Replaces rotate_iou_gpu_eval (second/core/non_max_suppression/nms_gpu.py:618-653; kernel
+ * :579-615, device functions :180-415, :564-576).  boxes [n,5], query_boxes [k,5] float32 rows
+ * (centre x, centre y, x size, y size, angle -- clockwise positive); out [n,k] float32 row-major:
+ * rotated-rectangle intersection of (query k, box n) divided by: -1 the union, 0 the query's area,
+ * 1 the box's area, 2 nothing (raw area).  Stateless; host pointers; `device` is the HIP device. */
+int pp_rotate_iou_eval(int device, const float* boxes, int64_t n, const float* query_boxes, int64_t k,
+                       int32_t criterion, float* out);
+/* Replaces d3_box_overlap (second/utils/eval.py:159-163 with its kernel :132-156): camera-frame
+ * boxes [n,7] / [k,7] float64 rows (x, y, z, l, h, w, ry); out [n,k] float64: BEV intersection
+ * (float32, as above with criterion 2) x height overlap / {union | box volume | query volume | 1}. */
+int pp_d3_box_overlap(int device, const double* boxes, int64_t n, const double* query_boxes, int64_t k,
+                      int32_t criterion, double* out);
+
 /* Device properties for reports: name (<=255 chars), CU count, bytes of HBM. */
 int pp_device_info(pp_handle h, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes);
 

@@ -65,3 +65,17 @@ def nms_sorted(boxes_sorted, thresh):
     keep = np.empty((max(n, 1),), dtype=np.int32)
     k = lib().oracle_nms_sorted(_p(boxes_sorted), ctypes.c_int(n), ctypes.c_float(thresh), _p(keep))
     return keep[:k].copy()
+
+
+def rotate_iou_eval(boxes, query_boxes, criterion=-1):
+    """second/core/non_max_suppression/nms_gpu.py:618-653 (rotate_iou_gpu_eval): [N,5] x [K,5] -> [N,K]."""
+    dtype = np.asarray(boxes).dtype
+    b = np.ascontiguousarray(boxes, dtype=np.float32)
+    q = np.ascontiguousarray(query_boxes, dtype=np.float32)
+    out = np.zeros((b.shape[0], q.shape[0]), dtype=np.float32)
+    if b.shape[0] and q.shape[0]:
+        L = lib()
+        L.oracle_rotate_iou_eval.restype = None
+        L.oracle_rotate_iou_eval(_p(b), ctypes.c_int64(b.shape[0]), _p(q), ctypes.c_int64(q.shape[0]),
+                                 ctypes.c_int(criterion), _p(out))
+    return out.astype(dtype)

@@ -130,3 +130,125 @@ int oracle_nms_sorted(const float* boxes, int n, float thresh, int32_t* keep) {
     free(remv);
     return nk;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Rotated-box IoU of the KITTI-style evaluator.
+ * Follows second/core/non_max_suppression/nms_gpu.py: rbbox_to_corners :361-385,
+ * point_in_quadrilateral :316-333, line_segment_intersection :240-275,
+ * quadrilateral_intersection :336-358, sort_vertex_in_convex_polygon :197-234, area :187-194,
+ * devRotateIoUEval :564-576, rotate_iou_kernel_eval :579-615 (note the kernel passes the QUERY
+ * box first).  All arithmetic is float32, as the float32 arrays of the reference make it;
+ * cos / sin / sqrt are evaluated in double and rounded (math.cos on a float32 scalar).
+ * ------------------------------------------------------------------------------------------ */
+static void riou_corners(const float* r, float* c) {
+    const float a_cos = (float)cos((double)r[4]), a_sin = (float)sin((double)r[4]);
+    const float cx = r[0], cy = r[1], xd = r[2], yd = r[3];
+    const float px[4] = {-xd / 2, -xd / 2, xd / 2, xd / 2};
+    const float py[4] = {-yd / 2, yd / 2, yd / 2, -yd / 2};
+    for (int i = 0; i < 4; ++i) {
+        c[2 * i] = a_cos * px[i] + a_sin * py[i] + cx;
+        c[2 * i + 1] = -a_sin * px[i] + a_cos * py[i] + cy;
+    }
+}
+
+static int riou_point_in_quad(float x, float y, const float* c) {
+    const float ab0 = c[2] - c[0], ab1 = c[3] - c[1];
+    const float ad0 = c[6] - c[0], ad1 = c[7] - c[1];
+    const float ap0 = x - c[0], ap1 = y - c[1];
+    const float abab = ab0 * ab0 + ab1 * ab1, abap = ab0 * ap0 + ab1 * ap1;
+    const float adad = ad0 * ad0 + ad1 * ad1, adap = ad0 * ap0 + ad1 * ap1;
+    return abab >= abap && abap >= 0 && adad >= adap && adap >= 0;
+}
+
+static int riou_seg_intersection(const float* p1, const float* p2, int i, int j, float* t) {
+    const float A0 = p1[2 * i], A1 = p1[2 * i + 1];
+    const float B0 = p1[2 * ((i + 1) % 4)], B1 = p1[2 * ((i + 1) % 4) + 1];
+    const float C0 = p2[2 * j], C1 = p2[2 * j + 1];
+    const float D0 = p2[2 * ((j + 1) % 4)], D1 = p2[2 * ((j + 1) % 4) + 1];
+    const float BA0 = B0 - A0, BA1 = B1 - A1, DA0 = D0 - A0, CA0 = C0 - A0, DA1 = D1 - A1, CA1 = C1 - A1;
+    const int acd = DA1 * CA0 > CA1 * DA0;
+    const int bcd = (D1 - B1) * (C0 - B0) > (C1 - B1) * (D0 - B0);
+    if (acd != bcd) {
+        const int abc = CA1 * BA0 > BA1 * CA0;
+        const int abd = DA1 * BA0 > BA1 * DA0;
+        if (abc != abd) {
+            const float DC0 = D0 - C0, DC1 = D1 - C1;
+            const float ABBA = A0 * B1 - B0 * A1, CDDC = C0 * D1 - D0 * C1;
+            const float DH = BA1 * DC0 - BA0 * DC1;
+            const float Dx = ABBA * DC0 - BA0 * CDDC, Dy = ABBA * DC1 - BA1 * CDDC;
+            t[0] = Dx / DH;
+            t[1] = Dy / DH;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+static float riou_inter(const float* r1, const float* r2) {
+    float c1[8], c2[8], ip[16 + 64], t[2];   /* 16 used by the reference; slack keeps a >8-point case in bounds */
+    int n = 0;
+    riou_corners(r1, c1);
+    riou_corners(r2, c2);
+    for (int i = 0; i < 4; ++i) {
+        if (riou_point_in_quad(c1[2 * i], c1[2 * i + 1], c2)) { ip[2 * n] = c1[2 * i]; ip[2 * n + 1] = c1[2 * i + 1]; ++n; }
+        if (riou_point_in_quad(c2[2 * i], c2[2 * i + 1], c1)) { ip[2 * n] = c2[2 * i]; ip[2 * n + 1] = c2[2 * i + 1]; ++n; }
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (riou_seg_intersection(c1, c2, i, j, t)) { ip[2 * n] = t[0]; ip[2 * n + 1] = t[1]; ++n; }
+    if (n > 0) {   /* sort_vertex_in_convex_polygon */
+        float cx = 0.f, cy = 0.f, vs[16 + 32];
+        for (int i = 0; i < n; ++i) { cx += ip[2 * i]; cy += ip[2 * i + 1]; }
+        cx /= (float)n;
+        cy /= (float)n;
+        for (int i = 0; i < n; ++i) {
+            float v0 = ip[2 * i] - cx, v1 = ip[2 * i + 1] - cy;
+            const float d = (float)sqrt((double)(v0 * v0 + v1 * v1));
+            v0 = v0 / d;
+            v1 = v1 / d;
+            if (v1 < 0) v0 = -2 - v0;
+            vs[i] = v0;
+        }
+        for (int i = 1; i < n; ++i) {
+            if (vs[i - 1] > vs[i]) {
+                const float temp = vs[i], tx = ip[2 * i], ty = ip[2 * i + 1];
+                int j = i;
+                while (j > 0 && vs[j - 1] > temp) {
+                    vs[j] = vs[j - 1];
+                    ip[2 * j] = ip[2 * j - 2];
+                    ip[2 * j + 1] = ip[2 * j - 1];
+                    --j;
+                }
+                vs[j] = temp;
+                ip[2 * j] = tx;
+                ip[2 * j + 1] = ty;
+            }
+        }
+    }
+    float area = 0.f;
+    for (int i = 0; i < n - 2; ++i) {
+        const float* a = ip;
+        const float* b = ip + 2 * i + 2;
+        const float* c = ip + 2 * i + 4;
+        area += fabsf(((a[0] - c[0]) * (b[1] - c[1]) - (a[1] - c[1]) * (b[0] - c[0])) / 2.0f);
+    }
+    return area;
+}
+
+/* out[n*K + k] = devRotateIoUEval(query[k], boxes[n], criterion)   (nms_gpu.py:611-613) */
+void oracle_rotate_iou_eval(const float* boxes, int64_t N, const float* qboxes, int64_t K, int criterion,
+                            float* out) {
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t k = 0; k < K; ++k) {
+            const float* r1 = qboxes + 5 * k;
+            const float* r2 = boxes + 5 * n;
+            const float a1 = r1[2] * r1[3], a2 = r2[2] * r2[3];
+            const float ai = riou_inter(r1, r2);
+            float v;
+            if (criterion == -1) v = ai / (a1 + a2 - ai);
+            else if (criterion == 0) v = ai / a1;
+            else if (criterion == 1) v = ai / a2;
+            else v = ai;
+            out[n * K + k] = v;
+        }
+}

@@ -32,6 +32,22 @@ _STUB_ROOTS = {
 }
 
 
+# reference-internal modules that cannot load here and are not on the path we pin: the prebuilt CUDA
+# extension nms.so (CPython 3.6 / libcudart 10.1) and the helper that would try to compile it
+_STUB_EXACT = {
+    "second.core.non_max_suppression.nms",
+    "second.utils.buildtools.pybind11_build",
+}
+
+_NP_TYPES = {"float32": np.float32, "float64": np.float64, "int32": np.int32, "int64": np.int64,
+             "uint64": np.uint64, "boolean": np.bool_}
+
+
+def _local_array(shape, dtype=np.float32):
+    # numba.cuda.local.array / shared.array when the "device function" runs as plain Python
+    return np.zeros(shape, dtype=dtype)
+
+
 def _identity_decorator(*args, **kwargs):
     # @jit / @jit(nopython=True) / @cuda.jit('sig', device=True)
     if len(args) == 1 and callable(args[0]) and not kwargs:
@@ -50,6 +66,13 @@ class _Anything(types.ModuleType):
         full = self.__name__ + "." + name
         if name in ("jit", "njit", "autojit", "vectorize", "guvectorize"):
             return _identity_decorator
+        if self.__name__.split(".")[0] == "numba":
+            if name in _NP_TYPES:
+                return _NP_TYPES[name]
+            if name == "prange":
+                return range
+            if name == "array" and self.__name__.split(".")[-1] in ("local", "shared"):
+                return _local_array
         if name in ("Model", "Layer", "Loss"):
             return type(name, (object,), {})
         if name == "function":
@@ -70,7 +93,7 @@ class _Anything(types.ModuleType):
 
 class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def find_spec(self, fullname, path, target=None):
-        if fullname.split(".")[0] in _STUB_ROOTS:
+        if fullname.split(".")[0] in _STUB_ROOTS or fullname in _STUB_EXACT:
             return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
         return None
 
@@ -101,6 +124,14 @@ def install():
 
     np.meshgrid = _meshgrid_list
     _installed = True
+
+
+def load_reference_eval():
+    """Returns (second.utils.eval, second.core.non_max_suppression.nms_gpu) for the AP-evaluator fixtures."""
+    install()
+    nms_gpu = importlib.import_module("second.core.non_max_suppression.nms_gpu")
+    ev = importlib.import_module("second.utils.eval")
+    return ev, nms_gpu
 
 
 def load_reference():
