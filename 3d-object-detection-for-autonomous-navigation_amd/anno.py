@@ -6,6 +6,9 @@ Mirrors, on the host, what `train.py evaluate` does with `net.predict`'s output:
   production post-filter  train.py:810-828  (score >= 0.45, camera -> lidar, +0.9 m lift for RViz)
 Pure numpy on <= 50 boxes per frame; nothing here touches the GPU.
 """
+import os
+import pickle
+
 import numpy as np
 
 _ANNO_KEYS = ("bbox", "name", "truncated", "occluded", "alpha", "dimensions", "location", "rotation_y", "score")
@@ -93,3 +96,18 @@ def production_boxes(dt_anno, r_rect, velo2cam, min_score=0.45, lift=0.9):
     boxes_camera = np.concatenate([a["location"], a["dimensions"], a["rotation_y"][..., np.newaxis]], axis=1)
     boxes_lidar = box_camera_to_lidar(boxes_camera, r_rect, velo2cam)
     return boxes_lidar[:, :3] + [0.0, 0.0, lift], boxes_lidar[:, 3:6], boxes_lidar[:, 6], a["score"]
+
+
+def save_results(dt_annos, out_dir, epoch_idx=None):
+    """train.py:867-873: the detections of a whole evaluation run as one pickle (protocol 2):
+    `result_epoch_<n>.pkl` during training-time evaluation, `result.pkl` otherwise.  Returns the path."""
+    name = "result.pkl" if epoch_idx is None else "result_epoch_{}.pkl".format(str(epoch_idx))
+    path = os.path.join(str(out_dir), name)
+    with open(path, "wb") as f:
+        pickle.dump(dt_annos, f, 2)
+    return path
+
+
+def load_results(path):
+    with open(str(path), "rb") as f:
+        return pickle.load(f)
