@@ -122,3 +122,14 @@ def test_nms_kernel_restatements_agree():
     # the +1 convention: two 0.6 m boxes 0.5 m apart overlap "more than 0.5" 
     b = np.array([[0, 0, .6, .6, .9], [.5, 0, 1.1, .6, .8], [3, 3, 3.6, 3.6, .7]], dtype=np.float32)
     assert list(c_oracle.nms_sorted(b, 0.5)) == [0, 2]
+
+
+def test_nms_iou_formula_matches_reference_device_function():
+    """iou_device (libraries/eval_helper_functions.py:553-564) executed as plain Python by the generator:
+    float32 there (numpy promotion) vs float64 under numba, hence a 1e-6 bar instead of equality."""
+    g = load_golden("ref_iou_device.npz")
+    b = g["boxes"]
+    for ri, i in enumerate(g["rows"]):
+        for ci, j in enumerate(g["cols"]):
+            assert abs(rn.nms_iou(b[i], b[j]) - g["iou"][ri, ci]) < 1e-6
+    assert (g["iou"] > 0.5).sum() > 100   # the `+1` makes metre-scale boxes within ~0.6 m "overlap" heavily

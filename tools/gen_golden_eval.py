@@ -120,3 +120,14 @@ res["coco_text"] = np.array(ev.get_coco_eval_result(gts, dts, ["Pedestrian"]))
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_kitti_eval.npz"), **res)
 print(text)
 print("coco:", str(res["coco_text"])[:200])
+
+# ---- the predict path's axis-aligned `+1` IoU (libraries/eval_helper_functions.py:553-564, iou_device) ----
+# Run as plain Python the float32 + integer-literal sums stay float32 (numpy promotion), whereas numba types
+# them float64: the fixture pins the formula (the `+1`, the clamps, the union) to ~1e-7, not the last bit.
+_, ehf = ref_shim.load_reference()
+ab = np.concatenate([rng.uniform(0, 6, (300, 2)), rng.uniform(0, 6, (300, 2))], 1).astype(np.float32)
+ab[:, 2:] = ab[:, :2] + rng.uniform(0.2, 1.5, (300, 2)).astype(np.float32)
+ious = np.array([[ehf.iou_device(ab[i], ab[j]) for j in range(0, 300, 7)] for i in range(0, 300, 5)], dtype=np.float64)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_iou_device.npz"), boxes=ab, iou=ious,
+                    rows=np.arange(0, 300, 5), cols=np.arange(0, 300, 7))
+print("iou_device:", ious.shape, float(ious.min()), float(ious.max()))
