@@ -132,4 +132,4 @@ def test_nms_iou_formula_matches_reference_device_function():
     for ri, i in enumerate(g["rows"]):
         for ci, j in enumerate(g["cols"]):
             assert abs(rn.nms_iou(b[i], b[j]) - g["iou"][ri, ci]) < 1e-6
-    assert (g["iou"] > 0.5).sum() > 100   # the `+1` makes metre-scale boxes within ~0.6 m "overlap" heavily
+    assert (g["iou"] > 0.5).sum() > 20 and (g["iou"] == 0.0).sum() > 20
