@@ -30,6 +30,7 @@
 #include "pp_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // 16-byte buffer load: address = SRD base + voffset (VGPR, bytes) + soffset (SGPR, bytes).  One VGPR
@@ -46,6 +47,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
 #define PX_TILE 128
 
 int g_num_cus = 256;   // set by pp_create from the device properties (persistent launches)
+
+// GEMM arithmetic: split-precision bf16 MFMA (default) or the float32 MFMA.  PP_GEMM_PREC=f32 selects the
+// latter; pp_bench_layer's ablation bits 2048 / 4096 force bf16x3 / f32.
+static bool split_precision(int ablate) {
+    static int dflt = -1;
+    if (dflt < 0) {
+        const char* e = getenv("PP_GEMM_PREC");
+        dflt = (e && e[0] == 'f') ? 0 : 1;
+    }
+    if (ablate & 2048) return true;
+    if (ablate & 4096) return false;
+    return dflt == 1;
+}
 #define KC 32
 #define LDS_STRIDE 36
 
@@ -53,6 +67,8 @@ struct GemmArgs {
     const float* in;
     const float* dw;
     const float* wt;
+    const unsigned short* wt16;   // split weights: three bf16 pieces, [cin/16][3][n_total][16] (or NULL)
+    int n_total;                  // rows of wt / wt16
     const float* bias;
     float* out;               // may be NULL when the layer's only consumer is the fused head GEMM
     float* head;              // fused head map [pixels][PP_HEAD_COLS]
@@ -645,6 +661,24 @@ __device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2,
     QUAD_XCH(r1, r3, b1, 0)
 }
 
+// float32 -> three bfloat16 pieces hi + mid + lo (round-to-nearest-even each; the two remainders are
+// exact float32 subtractions), 8 values at a time = one MFMA operand per piece.  a*b is then evaluated
+// as the six products whose weight is >= 2^-16 relative (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid)
+// on the bf16 matrix pipe with float32 accumulation: float32-equivalent accuracy (the dropped terms
+// are < 2^-24 relative) at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 16 channels.
+__device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        const float r1 = v[j] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        hi[j] = h;
+        mid[j] = m;
+        lo[j] = (__bf16)r2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Uniform-wave separable layer (every wave prepares AND multiplies).
 //
@@ -660,14 +694,17 @@ __device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2,
 // the scheduling grain is one wave per 32 pixels (tile quantisation costs less).  The epilogue
 // stores straight from the accumulators: for a fixed accumulator register the 32 lanes of a
 // half-wave hold 32 consecutive channels of one pixel = one full 128-byte line.
-template <int NT, int S, int WPS>
+// PREC 0: float32 MFMA (v_mfma_f32_32x32x2_f32); PREC 1: split-precision bf16 MFMA (see split_bf16x3).
+template <int NT, int S, int WPS, int PREC>
 __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     constexpr int KCH = 16, LSTR = KCH + 4, G = 4;
     constexpr int WW = S + 3;                        // input window width of 2 adjacent output pixels
     constexpr int NLD = 3 * WW;
     constexpr int SAW = 32 * LSTR;                   // one wave-private A buffer (floats)
-    constexpr int SB = NT * LSTR;
-    constexpr int NB4 = (NT * G + 255) / 256;        // weight float4 per thread per chunk
+    // weight tile in LDS: PREC 0 [NT][16 + 4] floats; PREC 1 [3 pieces][NT][16 bf16 = 8 floats], the two
+    // 16-byte halves of a row swapped on odd groups of 8 rows (conflict-free ds_read_b128 without padding)
+    constexpr int SB = (PREC == 0) ? NT * LSTR : 3 * NT * 8;
+    constexpr int NB4 = (PREC == 0) ? (NT * G + 255) / 256 : (NT * 6 + 255) / 256;   // 16-byte weight items per thread per chunk
     constexpr int NTILES = NT / 32;
     constexpr int KQ = KCH / 8;
     __shared__ __attribute__((aligned(16))) float smem[8 * SAW + 2 * SB + 9 * 256];
@@ -709,7 +746,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     // ---- staging role: lane (q, c4) owns output pixels pw + 2q, +1 and channels 4*c4..+3 of a chunk ----
     const int c4 = lane & 3, q = lane >> 2;
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
-    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(PREC == 0 ? (const void*)a.wt : (const void*)a.wt16);
     const int hw = a.px_h * a.px_w;
     const int rs4 = a.in_w * cin * 4, cin4 = cin * 4;
     unsigned aoff[NLD];
@@ -733,22 +770,35 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
                       (unsigned)(c4 * 16);                                                               \
         }                                                                                                \
     }
+    // weight staging items (16 bytes each): global byte offset and LDS float offset, fixed for the K loop
+    constexpr int NBI = (PREC == 0) ? NT * G : NT * 6;   // items per chunk
     unsigned boff[NB4];
+    int bdst[NB4];
 #pragma unroll
     for (int r = 0; r < NB4; ++r) {
-        const int e_ = tid + 256 * r;
-        boff[r] = (unsigned)(((n0 + (e_ / G) % NT) * cin + (e_ % G) * 4) * 4);
+        const int e_ = (tid + 256 * r) % NBI;
+        if (PREC == 0) {
+            boff[r] = (unsigned)(((n0 + e_ / G) * cin + (e_ % G) * 4) * 4);
+            bdst[r] = (e_ / G) * LSTR + (e_ % G) * 4;
+        } else {
+            const int piece = e_ / (NT * 2), rem = e_ % (NT * 2), row = rem >> 1, half = rem & 1;
+            boff[r] = (unsigned)(((piece * a.n_total + n0 + row) * 16 + half * 8) * 2);
+            bdst[r] = piece * (NT * 8) + row * 8 + ((half ^ ((row >> 3) & 1)) * 4);
+        }
     }
+    const unsigned bstep = (PREC == 0) ? (unsigned)(KCH * 4) : (unsigned)(3 * a.n_total * 32);   // bytes per K-chunk
     float4 rin[NLD];
-    float4 rb0, rb1;
-    rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    static_assert(NB4 <= 2, "weight prefetch registers");
+    float4 rb0, rb1, rb2;
+    rb0 = rb1 = rb2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_assert(NB4 <= 3, "weight prefetch registers");
 #define U_LOAD_CHUNK(KCIDX)                                                                              \
     {                                                                                                    \
         const unsigned so_ = (unsigned)(KCIDX) * (KCH * 4);                                              \
+        const unsigned sb_ = (unsigned)(KCIDX) * bstep;                                                  \
         _Pragma("unroll") for (int e = 0; e < NLD; ++e) rin[e] = buf_load16(rs_in, aoff[e], so_);        \
-        if ((NT * G) % 256 == 0 || tid < NT * G) rb0 = buf_load16(rs_wt, boff[0], so_);                  \
-        if (NB4 > 1) rb1 = buf_load16(rs_wt, boff[NB4 - 1], so_);                                        \
+        if (NBI % 256 == 0 || NB4 > 1 || tid < NBI) rb0 = buf_load16(rs_wt, boff[0], sb_);               \
+        if (NB4 > 1 && (NBI >= 512 || tid + 256 < NBI)) rb1 = buf_load16(rs_wt, boff[NB4 > 1 ? 1 : 0], sb_);  \
+        if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) rb2 = buf_load16(rs_wt, boff[NB4 > 2 ? 2 : 0], sb_);  \
     }
     // three cursors walk the stream of (tile, chunk) positions: loads are issued two positions ahead of
     // the MFMAs, staging runs one ahead
@@ -776,7 +826,27 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         bool tile_done = false;
         if (i >= 0) {
             // ---- MFMAs of position i out of buffer i & 1 ----
-            if (!(dbg & 1)) {
+            if (!(dbg & 1) && PREC == 1) {
+                const float* cA = sAw + (i & 1) * SAW + r32 * LSTR + h * (KCH / 2);
+                const float* cB = sB + (i & 1) * SB + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+                const float4 a0 = *reinterpret_cast<const float4*>(cA), a1 = *reinterpret_cast<const float4*>(cA + 4);
+                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                bf16x8 ah, am, al;
+                split_bf16x3(av, ah, am, al);
+#pragma unroll
+                for (int n = 0; n < NTILES; ++n) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);
+                    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+                }
+            }
+            if (!(dbg & 1) && PREC == 0) {
                 const float* cA = sAw + (i & 1) * SAW + r32 * LSTR + h * (KCH / 2);
                 const float* cB = sB + (i & 1) * SB + r32 * LSTR + h * (KCH / 2);
                 float4 a4[KQ];
@@ -819,10 +889,9 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
             float* dA = sAw + buf * SAW + (2 * q) * LSTR + c4 * 4;
             *reinterpret_cast<float4*>(dA) = o0;
             *reinterpret_cast<float4*>(dA + LSTR) = o1;
-            if ((NT * G) % 256 == 0 || tid < NT * G)
-                *reinterpret_cast<float4*>(sB + buf * SB + (tid / G) * LSTR + (tid % G) * 4) = rb0;
-            if (NB4 > 1)
-                *reinterpret_cast<float4*>(sB + buf * SB + ((tid + 256) / G) * LSTR + (tid % G) * 4) = rb1;
+            if (NBI % 256 == 0 || NB4 > 1 || tid < NBI) *reinterpret_cast<float4*>(sB + buf * SB + bdst[0]) = rb0;
+            if (NB4 > 1 && (NBI >= 512 || tid + 256 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 1 ? 1 : 0]) = rb1;
+            if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 2 ? 2 : 0]) = rb2;
             if (++st_kc == nchunks) st_kc = 0;
             if (i + 2 < total) {
                 if (ld_kc == 0) U_TILE_OFFSETS(ld_tile)
@@ -877,15 +946,20 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
 
 // persistent launch: WPS workgroups per CU (one wave per SIMD each), a multiple of 8 so that every XCD
 // gets the same number
-template <int NT, int S, int WPS>
+// WPS / WPB: workgroups per CU of the float32 / split-bf16 instantiation (register budgets differ)
+template <int NT, int S, int WPS, int WPB>
 static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
     const int ntiles = (a.M + 127) / 128;
     const int ny = n_total / NT;
-    int slots = (g_num_cus * WPS) / ny;
+    const bool bf = a.wt16 != nullptr && split_precision(a.dbg);
+    int slots = (g_num_cus * (bf ? WPB : WPS)) / ny;
     int gx = ntiles < slots ? ntiles : slots;
     gx = (gx + 7) & ~7;
     dim3 grid((unsigned)gx, ny);
-    hipLaunchKernelGGL((k_sep_u<NT, S, WPS>), grid, dim3(256), 0, s, a, ntiles);
+    if (bf)
+        hipLaunchKernelGGL((k_sep_u<NT, S, WPB, 1>), grid, dim3(256), 0, s, a, ntiles);
+    else
+        hipLaunchKernelGGL((k_sep_u<NT, S, WPS, 0>), grid, dim3(256), 0, s, a, ntiles);
 }
 
 template <int NT, int MODE>
@@ -990,6 +1064,7 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
     a.dbg = ablate;
     a.stamps = g_stamps;
     a.in = L.in; a.dw = L.d_dw; a.wt = L.d_wt; a.bias = L.d_bias; a.out = L.out;
+    a.wt16 = reinterpret_cast<const unsigned short*>(L.d_wt16); a.n_total = L.n_total;
     a.head = d_head; a.head_wt = L.d_head_wt; a.head_bias = L.d_head_bias; a.head_mode = L.head_mode;
     a.in_h = L.in_h; a.in_w = L.in_w; a.cin = L.cin;
     a.stride = L.stride; a.ld_out = L.ld_out; a.co_off = L.co_off;
@@ -1001,13 +1076,13 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
         if (use_ws(L) && sep_uniform(ablate)) {
             const int nt = sep_u_nt(L, batch);
             if (L.stride == 1) {
-                if (nt == 128) launch_u<128, 1, 3>(a, L.n_total, s);
-                else if (nt == 64) launch_u<64, 1, 4>(a, L.n_total, s);
-                else launch_u<32, 1, 4>(a, L.n_total, s);
+                if (nt == 128) launch_u<128, 1, 3, 2>(a, L.n_total, s);
+                else if (nt == 64) launch_u<64, 1, 4, 3>(a, L.n_total, s);
+                else launch_u<32, 1, 4, 4>(a, L.n_total, s);
             } else {
-                if (nt == 128) launch_u<128, 2, 2>(a, L.n_total, s);
-                else if (nt == 64) launch_u<64, 2, 3>(a, L.n_total, s);
-                else launch_u<32, 2, 4>(a, L.n_total, s);
+                if (nt == 128) launch_u<128, 2, 2, 2>(a, L.n_total, s);
+                else if (nt == 64) launch_u<64, 2, 3, 3>(a, L.n_total, s);
+                else launch_u<32, 2, 4, 3>(a, L.n_total, s);
             }
         } else if (use_ws(L)) {
             if (L.stride == 1) {

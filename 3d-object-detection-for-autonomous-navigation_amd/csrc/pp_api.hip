@@ -201,6 +201,43 @@ int upload(pp_engine* e, float** d, const std::vector<float>& h) {
     return PP_OK;
 }
 
+// Split-precision operand for the bf16 matrix pipe: every float32 weight w becomes three bfloat16
+// pieces hi + mid + lo (round-to-nearest-even each, 24 mantissa bits in total, exact for finite w),
+// laid out [cin / 16][piece][n_total][16] so that one K-chunk's tile of one piece is contiguous
+// (what k_sep_u / the deconv kernel stage into LDS).  Returned as raw 16-bit words packed in floats.
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+std::vector<float> split_weights_bf16x3(const std::vector<float>& wt, int n_total, int cin) {
+    std::vector<uint16_t> out((size_t)n_total * cin * 3);
+    const int nch = cin / 16;
+    for (int n = 0; n < n_total; ++n)
+        for (int c = 0; c < cin; ++c) {
+            const float w = wt[(size_t)n * cin + c];
+            const uint16_t hi = bf16_rne(w);
+            const float r1 = w - bf16_to_f32(hi);
+            const uint16_t mid = bf16_rne(r1);
+            const float r2 = r1 - bf16_to_f32(mid);
+            const uint16_t lo = bf16_rne(r2);
+            const int kc = c / 16, cc = c % 16;
+            const uint16_t pcs[3] = {hi, mid, lo};
+            for (int p = 0; p < 3; ++p) out[(((size_t)kc * 3 + p) * n_total + n) * 16 + cc] = pcs[p];
+        }
+    (void)nch;
+    std::vector<float> packed(out.size() / 2);
+    memcpy(packed.data(), out.data(), out.size() * 2);
+    return packed;
+}
+
 // ---- stage pipelines (all enqueue on e->stream) ----
 int run_voxelize(pp_engine* e, int batch, int max_n) {
     {
@@ -608,6 +645,7 @@ int pp_finalize_weights(pp_handle e) {
                 for (int co = 0; co < L.cout; ++co) wt[(size_t)co * L.cin + ci] = (*pw)[(size_t)ci * L.cout + co] * sc[co];
             int st = upload(e, &L.d_dw, *dw); if (st) return st;
             st = upload(e, &L.d_wt, wt); if (st) return st;
+            if (L.cin % 16 == 0) { st = upload(e, &L.d_wt16, split_weights_bf16x3(wt, L.n_total, L.cin)); if (st) return st; }
             st = upload(e, &L.d_bias, sh); if (st) return st;
             ++li;
         } else if (L.kind == LAYER_DECONV) {

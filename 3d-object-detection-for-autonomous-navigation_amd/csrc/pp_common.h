@@ -39,6 +39,7 @@ struct LayerDesc {
     int n_total;          // GEMM N: cout (sep), k*k*cout (deconv), 32 (head, zero padded)
     float* d_dw;          // [9][cin] depthwise taps (sep)
     float* d_wt;          // [n_total][cin] BN-folded, transposed
+    float* d_wt16;        // the same weights as three bf16 pieces, [cin/16][3][n_total][16] 16-bit words (or NULL)
     float* d_bias;        // [cout] (sep/deconv: folded BN shift) or [32] (head)
     const float* in;      // input activation  [B, in_h, in_w, cin]
     float* out;           // output base
