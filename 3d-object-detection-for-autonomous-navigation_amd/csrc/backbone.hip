@@ -73,6 +73,7 @@ struct GemmArgs {
     float* out;               // may be NULL when the layer's only consumer is the fused head GEMM
     float* head;              // fused head map [pixels][PP_HEAD_COLS]
     const float* head_wt;     // [PP_HEAD_COLS][cout] (deconv with fused heads)
+    const float* head_wt16;   // the same slice as three bf16 pieces, [cout/16][3][PP_HEAD_COLS][16] 16-bit words
     const float* head_bias;   // [PP_HEAD_COLS]
     int head_mode;            // 0: none, 1: head = partial + bias, 2: head += partial
     int M;                // GEMM rows (pixels) < 2^31 (checked by the launcher)
@@ -962,6 +963,277 @@ static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
         hipLaunchKernelGGL((k_sep_u<NT, S, WPS, 0>), grid, dim3(256), 0, s, a, ntiles);
 }
 
+// Epilogue of one 128-pixel deconv tile (see k_deconv_u): so = this wave's [32][36] staging tile.
+template <int NT>
+__device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (&acc)[NT / 32], const float (&bias_r)[NT / 32],
+                                                     float hbias, int tile, int wave, int lane, int cbase, int delta,
+                                                     const int* opix_tab, float* so, const float* sHW) {
+    constexpr int NTILES = NT / 32, ESTR = 36;
+    const int h = lane >> 5, r32 = lane & 31;
+    const int pw = tile * 128 + wave * 32;
+    if ((a.dbg & 4) || pw >= a.M) return;
+    const bool full = pw + 32 <= a.M;   // wave-uniform
+    const int qi = lane & 3, qj = r32 >> 2;
+    int orow[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) orow[g] = opix_tab[wave * 32 + 8 * g + 4 * h + qi] + delta;
+    const bool heads = a.head_mode != 0;
+    float hold[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hold[r] = 0.f;
+    if (a.head_mode == 2) {   // partial sums of the earlier branches: loads issued now, used at the end
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (full || pw + row < a.M)
+                hold[r] = a.head[(size_t)(opix_tab[wave * 32 + row] + delta) * PP_HEAD_COLS + r32];
+        }
+    }
+    f32x16 hacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+    float* dst = (a.out != nullptr) ? a.out + a.co_off + cbase + qj * 4 : nullptr;
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[n][r] + bias_r[n], 0.f);
+        if (heads) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) so[((r & 3) + 8 * (r >> 2) + 4 * h) * ESTR + r32] = v[r];
+#pragma unroll
+            for (int g16 = 0; g16 < 2; ++g16) {
+                const float4 x0 = *reinterpret_cast<const float4*>(so + r32 * ESTR + g16 * 16 + h * 8);
+                const float4 x1 = *reinterpret_cast<const float4*>(so + r32 * ESTR + g16 * 16 + h * 8 + 4);
+                const float av[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                bf16x8 ah, am, al;
+                split_bf16x3(av, ah, am, al);
+                const float* hB = sHW + ((n * 2 + g16) * 3 * 32 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hB);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(hB + 32 * 8);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(hB + 2 * 32 * 8);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, hacc, 0, 0, 0);
+            }
+        }
+        if (dst != nullptr) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float x0 = v[4 * g + 0], x1 = v[4 * g + 1], x2 = v[4 * g + 2], x3 = v[4 * g + 3];
+                quad_transpose4(x0, x1, x2, x3, lane);
+                if (full || pw + 8 * g + 4 * h + qi < a.M)
+                    *reinterpret_cast<float4*>(dst + (size_t)orow[g] * a.ld_out + n * 32) = make_float4(x0, x1, x2, x3);
+            }
+        }
+    }
+    if (heads) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (full || pw + row < a.M)
+                a.head[(size_t)(opix_tab[wave * 32 + row] + delta) * PP_HEAD_COLS + r32] = hacc[r] + hbias + hold[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Uniform-wave Conv2DTranspose (kernel == stride) + BN + ReLU [+ fused SSD heads], split-precision bf16.
+//
+// Same skeleton as k_sep_u (persistent 4-wave workgroups, wave w owns input pixels 32w..32w+31 of a
+// 128-pixel tile, one barrier per 16-channel K-chunk for the shared weight tile), but the A operand
+// needs no LDS at all: lane (r, h) of the MFMA layout owns pixel r, channels 8h..8h+7 of the chunk,
+// i.e. 32 contiguous bytes of the input row, loaded straight into registers two K-chunks ahead (two
+// register sets alternate; every layer has an even number of chunks), split into three bf16 pieces and
+// multiplied.  blockIdx.y selects NT of the k*k*cout GEMM columns (one tap when NT == cout).
+// Epilogue: bias + ReLU, 4 x 4 DPP transposes, 16-byte stores into the pixel-shuffled position of the
+// concat buffer (output pixel index per input pixel from a small double-buffered LDS table that is
+// filled one tile ahead).  With fused heads the activated 32 x 32 blocks are turned around through a
+// per-wave LDS staging tile into A operands, split, and multiplied with this branch's slice of the
+// head kernels (three bf16 pieces, resident in LDS for the whole launch); the 32-column partial result
+// is added to the head map by a race-free read-modify-write (the three deconv launches run in stream
+// order and a (pixel, column) pair is touched by exactly one wave per launch).
+template <int NT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
+    constexpr int KCH = 16;
+    constexpr int NTILES = NT / 32;
+    constexpr int SB = 3 * NT * 8;                       // one weight buffer: [3 pieces][NT][8 floats]
+    constexpr int NBI = NT * 6;                          // 16-byte weight items per chunk
+    constexpr int NB4 = (NBI + 255) / 256;
+    constexpr int ESTR = 36;                             // head staging row stride (floats)
+    constexpr int SHW = (NT / 16) * 3 * 32 * 8;          // head weights: [NT/16][3][32 cols][8 floats]
+    __shared__ __attribute__((aligned(16))) float sB[2 * SB];
+    __shared__ __attribute__((aligned(16))) float sHW[SHW];
+    __shared__ __attribute__((aligned(16))) float sStage[4 * 32 * ESTR];
+    __shared__ int s_opix[2][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, r32 = lane & 31;
+    const int dbg = a.dbg;
+
+    const int xcd = blockIdx.x & 7, gl = blockIdx.x >> 3, GL = gridDim.x >> 3;
+    const int tbase = (int)(((long long)xcd * ntiles) >> 3), tend = (int)(((long long)(xcd + 1) * ntiles) >> 3);
+    const int first = tbase + gl;
+    if (first >= tend) return;
+    const int ntl = (tend - first + GL - 1) / GL;
+    const int n0 = blockIdx.y * NT;
+    const int cin = a.cin;
+    const int nchunks = cin / KCH;                       // even (cin % 32 == 0, checked by the launcher)
+    const int total = ntl * nchunks;
+    const int tap = n0 / a.cout, cbase = n0 - tap * a.cout;
+    const int ti = tap / a.k;
+    const int delta = ti * (a.px_w * a.k) + (tap - ti * a.k);   // output-pixel offset of this tap
+    const bool heads = a.head_mode != 0;
+
+    // output pixel (tap (0,0)) of every input pixel of a tile -> s_opix[slot]
+    const int hwpx = a.px_h * a.px_w;
+#define D_FILL_OPIX(TILE, SLOT)                                                         \
+    if (tid < 128) {                                                                    \
+        const int pix_ = min((TILE) * 128 + tid, a.M - 1);                              \
+        const int b_ = pix_ / hwpx, rem_ = pix_ - b_ * hwpx;                            \
+        const int y_ = rem_ / a.px_w, x_ = rem_ - y_ * a.px_w;                          \
+        s_opix[SLOT][tid] = (b_ * a.px_h * a.k + y_ * a.k) * (a.px_w * a.k) + x_ * a.k; \
+    }
+    D_FILL_OPIX(first, 0)
+    if (heads) {   // this branch's head-kernel slice, three bf16 pieces, into LDS once
+        for (int e = tid; e < SHW / 4; e += 256)   // 16-byte halves swapped on odd groups of 8 columns (bank conflicts)
+            reinterpret_cast<float4*>(sHW)[e ^ ((e >> 4) & 1)] = reinterpret_cast<const float4*>(a.head_wt16)[e];
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt16);
+    unsigned boff[NB4];
+    int bdst[NB4];
+#pragma unroll
+    for (int r = 0; r < NB4; ++r) {
+        const int e_ = (tid + 256 * r) % NBI;
+        const int piece = e_ / (NT * 2), rem = e_ % (NT * 2), row = rem >> 1, half = rem & 1;
+        boff[r] = (unsigned)(((piece * a.n_total + n0 + row) * 16 + half * 8) * 2);
+        bdst[r] = piece * (NT * 8) + row * 8 + ((half ^ ((row >> 3) & 1)) * 4);
+    }
+    const unsigned bstep = (unsigned)(3 * a.n_total * 32);
+    float4 rb0, rb1, rb2;
+    rb0 = rb1 = rb2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_assert(NB4 <= 3, "weight prefetch registers");
+#define D_LOAD_B(KCIDX)                                                                                  \
+    {                                                                                                    \
+        const unsigned sb_ = (unsigned)(KCIDX) * bstep;                                                  \
+        if (NBI % 256 == 0 || NB4 > 1 || tid < NBI) rb0 = buf_load16(rs_wt, boff[0], sb_);               \
+        if (NB4 > 1 && (NBI >= 512 || tid + 256 < NBI)) rb1 = buf_load16(rs_wt, boff[NB4 > 1 ? 1 : 0], sb_);  \
+        if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) rb2 = buf_load16(rs_wt, boff[NB4 > 2 ? 2 : 0], sb_);  \
+    }
+#define D_STORE_B(BUF)                                                                                   \
+    {                                                                                                    \
+        if (NBI % 256 == 0 || NB4 > 1 || tid < NBI) *reinterpret_cast<float4*>(sB + (BUF) * SB + bdst[0]) = rb0;  \
+        if (NB4 > 1 && (NBI >= 512 || tid + 256 < NBI)) *reinterpret_cast<float4*>(sB + (BUF) * SB + bdst[NB4 > 1 ? 1 : 0]) = rb1;  \
+        if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) *reinterpret_cast<float4*>(sB + (BUF) * SB + bdst[NB4 > 2 ? 2 : 0]) = rb2;  \
+    }
+    // A operand: this lane's 32 bytes of a chunk; byte offset of the tile's row (0 -> zero header when
+    // the pixel is past the end)
+    int ld_tile = first, ld_kc = 0;
+    unsigned avo;
+#define D_TILE_AOFF(TILE)                                                                                \
+    {                                                                                                    \
+        const int pix_ = (TILE) * 128 + wave * 32 + r32;                                                 \
+        avo = (pix_ < a.M && !(dbg & 8)) ? (unsigned)(pix_ * cin + h * 8) * 4u + PP_ZPAD_FLOATS * 4u : (unsigned)(h * 32); \
+    }
+#define D_LOAD_A(R0, R1)                                                                                 \
+    {                                                                                                    \
+        if (ld_kc == 0) D_TILE_AOFF(ld_tile)                                                             \
+        const unsigned so_ = (unsigned)ld_kc * (KCH * 4);                                                \
+        R0 = buf_load16(rs_in, avo, so_);                                                                \
+        R1 = buf_load16(rs_in, avo + 16u, so_);                                                          \
+        if (++ld_kc == nchunks) { ld_kc = 0; ld_tile += GL; }                                            \
+    }
+    float4 ra0, ra1, rc0, rc1;           // raw A of even / odd stream positions
+    D_LOAD_A(ra0, ra1)                   // position 0
+    D_LOAD_A(rc0, rc1)                   // position 1 (total >= 2)
+    D_LOAD_B(0)
+    int lb_kc = 1;                       // chunk index of the next weight tile to load
+
+    f32x16 acc[NTILES];
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    float bias_r[NTILES];
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n) bias_r[n] = a.bias[cbase + n * 32 + r32];
+    const float hbias = (a.head_mode == 1) ? a.head_bias[r32] : 0.f;
+    int mm_tile = first, mm_kc = 0, mm_slot = 0;
+    __syncthreads();                     // head weights / opix table visible
+    D_STORE_B(0)
+    D_LOAD_B(lb_kc)
+    if (++lb_kc == nchunks) lb_kc = 0;
+    __syncthreads();
+
+    // one stream position: multiply chunk i (raw A in RA0/RA1), prefetch position i+2 into the same registers
+#define D_STEP(I, RA0, RA1)                                                                              \
+    {                                                                                                    \
+        const int i_ = (I);                                                                              \
+        const float av_[8] = {RA0.x, RA0.y, RA0.z, RA0.w, RA1.x, RA1.y, RA1.z, RA1.w};                   \
+        bf16x8 ah_, am_, al_;                                                                            \
+        split_bf16x3(av_, ah_, am_, al_);                                                                \
+        if (i_ + 2 < total) D_LOAD_A(RA0, RA1)                                                           \
+        if (!(dbg & 1)) {                                                                                \
+            const float* cB_ = sB + (i_ & 1) * SB + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);              \
+            _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                         \
+                const bf16x8 bh_ = *reinterpret_cast<const bf16x8*>(cB_ + n * 32 * 8);                   \
+                const bf16x8 bm_ = *reinterpret_cast<const bf16x8*>(cB_ + NT * 8 + n * 32 * 8);          \
+                const bf16x8 bl_ = *reinterpret_cast<const bf16x8*>(cB_ + 2 * NT * 8 + n * 32 * 8);      \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am_, bm_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am_, bh_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bm_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, acc[n], 0, 0, 0);             \
+            }                                                                                            \
+        }                                                                                                \
+        if (i_ + 1 < total) {   /* weight tile of position i+1 -> LDS, loads of position i+2 */         \
+            D_STORE_B((i_ + 1) & 1)                                                                      \
+            if (i_ + 2 < total) D_LOAD_B(lb_kc)                                                          \
+            if (++lb_kc == nchunks) lb_kc = 0;                                                           \
+        }                                                                                                \
+        if (++mm_kc == nchunks) {                                                                        \
+            deconv_tile_epilogue<NT>(a, acc, bias_r, hbias, mm_tile, wave, lane, cbase, delta,       \
+                                     s_opix[mm_slot], sStage + wave * 32 * ESTR, sHW);                   \
+            _Pragma("unroll") for (int n = 0; n < NTILES; ++n)                                           \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;                          \
+            mm_kc = 0;                                                                                   \
+            mm_tile += GL;                                                                               \
+            mm_slot ^= 1;                                                                                \
+        } else if (mm_kc == 1 && mm_tile + GL < tend) {                                                  \
+            D_FILL_OPIX(mm_tile + GL, mm_slot ^ 1)   /* table of the next tile, one tile ahead */        \
+        }                                                                                                \
+        __syncthreads();                                                                                 \
+    }
+    for (int i = 0; i < total; i += 2) {
+        D_STEP(i, ra0, ra1)
+        D_STEP(i + 1, rc0, rc1)
+    }
+#undef D_STEP
+#undef D_LOAD_A
+#undef D_TILE_AOFF
+#undef D_STORE_B
+#undef D_LOAD_B
+#undef D_FILL_OPIX
+}
+
+template <int NT>
+static void launch_deconv_u(const GemmArgs& a, int n_total, hipStream_t s) {
+    constexpr int WPS = 2;
+    const int ntiles = (a.M + 127) / 128;
+    const int ny = n_total / NT;
+    int slots = (g_num_cus * WPS) / ny;
+    if (slots < 8) slots = 8;
+    int gx = ntiles < slots ? ntiles : slots;
+    gx = (gx + 7) & ~7;
+    dim3 grid((unsigned)gx, ny);
+    hipLaunchKernelGGL((k_deconv_u<NT, WPS>), grid, dim3(256), 0, s, a, ntiles);
+}
+
 template <int NT, int MODE>
 static void launch_t(const GemmArgs& a, int n_total, hipStream_t s) {
     const unsigned mt = (unsigned)((a.M + PX_TILE - 1) / PX_TILE);
@@ -1024,6 +1296,15 @@ static bool use_ws(const LayerDesc& L) {
     return (L.stride == 1 || L.stride == 2) && (L.out_w % 2 == 0);
 }
 
+// the split-precision uniform-wave deconv kernel runs when its operands exist (cin % 32 == 0: an even
+// number of 16-channel chunks) and, with fused heads, when one column tile covers the tap (NT == cout)
+static bool deconv_uniform(const LayerDesc& L, int ablate) {
+    if (L.kind != LAYER_DECONV || L.d_wt16 == nullptr || L.cin % 32 != 0 || !split_precision(ablate)) return false;
+    if (ablate & 32) return false;
+    if (L.head_mode != 0 && (L.d_head_wt16 == nullptr || !(L.cout == 32 || L.cout == 64 || L.cout == 128))) return false;
+    return true;
+}
+
 // a deconv can carry the fused head GEMM when one workgroup column covers the tap's whole channel
 // range (NT == cout) and the wave-specialised kernel runs it
 bool deconv_can_fuse_heads(const LayerDesc& L) {
@@ -1041,8 +1322,13 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
     char buf[64];
     if (L.kind == LAYER_SEP && use_ws(L) && sep_uniform(0)) {
         const int unt = sep_u_nt(L, batch);
-        const int wps = (L.stride == 1) ? (unt == 128 ? 3 : 4) : (unt == 128 ? 2 : (unt == 64 ? 3 : 4));
-        snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d>", unt, L.stride, wps);
+        const bool bf = L.d_wt16 != nullptr && split_precision(0);
+        int wps;   // workgroups per CU of the instantiation launch_layer picks (launch_u<NT, S, WPS, WPB>)
+        if (L.stride == 1) wps = bf ? (unt == 128 ? 2 : (unt == 64 ? 3 : 4)) : (unt == 128 ? 3 : 4);
+        else wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 2 : (unt == 64 ? 3 : 4));
+        snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d,%d>", unt, L.stride, wps, bf ? 1 : 0);
+    } else if (deconv_uniform(L, 0)) {
+        snprintf(buf, sizeof(buf), "k_deconv_u<%d,2>", nt);
     } else if (use_ws(L)) {
         const int pxb = ws_small_tile(layer_rows(L, batch), L.n_total, nt) ? 64 : 128;
         snprintf(buf, sizeof(buf), "k_gemm_ws<%d,%d,%d,%d>", nt, mode, mode == 0 ? L.stride : 1, pxb);
@@ -1066,6 +1352,7 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
     a.in = L.in; a.dw = L.d_dw; a.wt = L.d_wt; a.bias = L.d_bias; a.out = L.out;
     a.wt16 = reinterpret_cast<const unsigned short*>(L.d_wt16); a.n_total = L.n_total;
     a.head = d_head; a.head_wt = L.d_head_wt; a.head_bias = L.d_head_bias; a.head_mode = L.head_mode;
+    a.head_wt16 = L.d_head_wt16;
     a.in_h = L.in_h; a.in_w = L.in_w; a.cin = L.cin;
     a.stride = L.stride; a.ld_out = L.ld_out; a.co_off = L.co_off;
     a.k = L.k; a.cout = L.cout;
@@ -1103,7 +1390,11 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
         a.px_h = L.in_h; a.px_w = L.in_w; a.epi = 1;
         a.M = batch * L.in_h * L.in_w;
         if (L.cout % 32 != 0) return PP_ERR_UNSUPPORTED;
-        if (use_ws(L)) {
+        if (deconv_uniform(L, ablate)) {
+            if (L.cout % 128 == 0) launch_deconv_u<128>(a, L.n_total, s);
+            else if (L.cout % 64 == 0) launch_deconv_u<64>(a, L.n_total, s);
+            else launch_deconv_u<32>(a, L.n_total, s);
+        } else if (use_ws(L)) {
             if (L.cout % 128 == 0) launch_ws<128, 1, 1>(a, L.n_total, s);
             else if (L.cout % 64 == 0) launch_ws<64, 1, 1>(a, L.n_total, s);
             else launch_ws<32, 1, 1>(a, L.n_total, s);

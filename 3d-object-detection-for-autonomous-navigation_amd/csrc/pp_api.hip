@@ -658,12 +658,14 @@ int pp_finalize_weights(pp_handle e) {
                 for (int ci = 0; ci < L.cin; ++ci) wt[n * L.cin + ci] = (*k)[n * L.cin + ci] * sc[co];
             }
             int st = upload(e, &L.d_wt, wt); if (st) return st;
+            if (L.cin % 16 == 0) { st = upload(e, &L.d_wt16, split_weights_bf16x3(wt, L.n_total, L.cin)); if (st) return st; }
             st = upload(e, &L.d_bias, sh); if (st) return st;
             if (L.head_mode != 0) {   // this branch's [PP_HEAD_COLS][cout] slice of the head matrix
                 std::vector<float> hw((size_t)PP_HEAD_COLS * L.cout);
                 for (int o = 0; o < PP_HEAD_COLS; ++o)
                     for (int c = 0; c < L.cout; ++c) hw[(size_t)o * L.cout + c] = headw[(size_t)o * e->CC + L.co_off + c];
                 st = upload(e, &L.d_head_wt, hw); if (st) return st;
+                if (L.cout % 16 == 0) { st = upload(e, &L.d_head_wt16, split_weights_bf16x3(hw, PP_HEAD_COLS, L.cout)); if (st) return st; }
                 st = upload(e, &L.d_head_bias, headb); if (st) return st;
             }
             ++bi; li = 0;

@@ -49,6 +49,7 @@ struct LayerDesc {
     int head_mode;
     float* d_head_wt;     // [PP_HEAD_COLS][cout] slice of the head kernels, transposed
     float* d_head_bias;   // [PP_HEAD_COLS]
+    float* d_head_wt16;   // d_head_wt as three bf16 pieces, [cout/16][3][PP_HEAD_COLS][16] 16-bit words (or NULL)
     const char* name;
 };
 
