@@ -816,6 +816,9 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     const int h = lane >> 5, r32 = lane & 31;
+    float bias_r[NTILES];   // loaded once: a global load inside the epilogue would sit on its critical path
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n) bias_r[n] = a.bias[n0 + n * 32 + r32];
     __syncthreads();   // depthwise taps visible
     U_STAMP(1)
 
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
                 const bool full = pw + 32 <= a.M;             // wave-uniform
 #pragma unroll
                 for (int n = 0; n < NTILES; ++n) {
-                    const float bvn = a.bias[n0 + n * 32 + r32];
+                    const float bvn = bias_r[n];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);

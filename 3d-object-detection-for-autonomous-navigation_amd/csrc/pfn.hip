@@ -28,6 +28,8 @@
 // (3-4 FMAs per point and channel instead of 8-9; working in pillar-local x', y'
 // keeps every product small, so the rounding error stays below the reference's
 // own evaluation of the raw-coordinate terms), and max_j ReLU(a_j) = ReLU(max_j a_j).
+#include <stdlib.h>
+
 #include "pp_common.h"
 
 template <int N>
@@ -210,14 +212,205 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Fused path (CSR source), second generation: memory round trips hoisted out of the per-pillar
+// loop, one pass over the points.  A wavefront owns PFN2_CW consecutive canvas cells = up to
+// PFN2_CW * nz pillar slots (cell-major).  (0) one lane per slot reads the cell map and the slot's
+// CSR range -- two dependent loads for ALL slots at once -- and derives its pillar centre; (1) a
+// wave prefix sum lays the slots' points out as one stream; (2) the stream is read 64 points at a
+// time (one point per lane: CSR index, then the point; the next batch is prefetched while the
+// current one is used); (3) the wave walks the stream in order with wave-uniform control flow:
+// pillar-local coordinates are broadcast with v_readlane, every lane keeps the running max of
+//     a_j = x'_j (Wx+Wcx+Wpx) + y'_j (Wy+Wcy+Wpy) + z_j (Wz+Wcz) [+ i_j Wi]
+// for its channels and the running coordinate sums; since the per-pillar constant K (bias, centre
+// and mean terms) does not depend on j, max_j (K + a_j) = K + max_j a_j, so the mean is only needed
+// when the slot ends: no second pass over the points.  Slot / cell boundaries finalise (ReLU, pad
+// constant, sum over z) and write the 4C-byte canvas row -- zeros for cells no pillar maps to.
+#define PFN2_CW 8
+template <int CPL, int F>
+__global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
+    constexpr int FA = F + 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int ncanvas = p.ny * p.nx;
+    const int cell0 = (blockIdx.x * 4 + wave) * PFN2_CW;
+    if (cell0 >= ncanvas) return;
+    const int ncells = min(PFN2_CW, ncanvas - cell0);
+    const int nz = p.nz;
+    const int NS = ncells * nz;                       // slots of this wave (<= 64, checked by the launcher)
+    const int C = p.C, T = p.T;
+    const int ch0 = lane * CPL;
+    const bool ch_ok = ch0 < C;
+
+    // ---- (0) slot metadata, one lane per slot ----
+    const int n0 = p.offsets[b];
+    const int* ps = p.pillar_start + (size_t)b * (p.max_voxels + 1);
+    int pid = -1, start = 0, cnt = 0, slot_cell = 0;
+    float slot_cx = 0.f, slot_cy = 0.f;
+    if (lane < NS) {
+        const int c = lane / nz, z = lane - c * nz;
+        slot_cell = c;
+        pid = p.cellmap[((size_t)b * nz + z) * ncanvas + cell0 + c];
+        if (pid >= 0) {
+            start = ps[pid];
+            cnt = min(ps[pid + 1] - start, T);
+        }
+        const int cell = cell0 + c;
+        const int yi = cell / p.nx, xi = cell - yi * p.nx;
+        slot_cx = __fadd_rn(__fmul_rn((float)xi, p.vx), p.x_off);      // model/pointpillars.py:156-171
+        slot_cy = __fadd_rn(__fmul_rn((float)yi, p.vy), p.y_off);
+    }
+    // weights of this lane's channels (independent of the loads above)
+    float w[FA][CPL], bias[CPL];
+#pragma unroll
+    for (int k = 0; k < FA; ++k)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) w[k][q] = ch_ok ? p.w[k * C + ch0 + q] : 0.f;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) bias[q] = ch_ok ? p.bias[ch0 + q] : 0.f;
+    float wsx[CPL], wsy[CPL], wsz[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        wsx[q] = (w[0][q] + w[F + 0][q]) + w[F + 3][q];
+        wsy[q] = (w[1][q] + w[F + 1][q]) + w[F + 4][q];
+        wsz[q] = w[2][q] + w[F + 2][q];
+    }
+
+    // ---- (1) stream layout: inclusive prefix of cnt over the slot lanes ----
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    const int excl = incl - cnt;
+    const int tot = __builtin_amdgcn_readlane(incl, 63);
+    const unsigned* sidx = p.sorted_idx + n0;
+    const float* src = p.pts + (size_t)n0 * F;
+
+    // one batch = stream positions base..base+63, one per lane: slot, coordinates
+    struct Batch { int slot; float x, y, z, i; };
+    auto load_batch = [&](int base) -> Batch {
+        Batch r;
+        r.slot = -1; r.x = r.y = r.z = r.i = 0.f;
+        const int g = base + lane;
+        int sl = 0;
+        for (int s = 0; s < NS; ++s) sl += (g >= __builtin_amdgcn_readlane(incl, s)) ? 1 : 0;
+        sl = min(sl, NS - 1);
+        const int st = __shfl(start, sl), ex = __shfl(excl, sl);
+        if (g < tot) {
+            r.slot = sl;
+            const float* q = src + (size_t)sidx[st + (g - ex)] * F;
+            r.x = q[0]; r.y = q[1]; r.z = q[2];
+            if (F > 3) r.i = q[F - 1];
+        }
+        return r;
+    };
+
+    // ---- (3) walk the stream ----
+    float* cbase = p.canvas + ((size_t)b * ncanvas + cell0) * C;
+    float acc[CPL], m[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) { acc[q] = 0.f; m[q] = -3.0e38f; }
+    int cur_slot = -1, cur_cell = 0;
+    float cxf = 0.f, cyf = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;      // wave-uniform values (same in every lane)
+    auto write_cell = [&](int c) {
+        if (ch_ok) {
+            float* dst = cbase + (size_t)c * C + ch0;
+            if constexpr (CPL == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            else if constexpr (CPL == 2) *reinterpret_cast<float2*>(dst) = make_float2(acc[0], acc[1]);
+            else dst[0] = acc[0];
+        }
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
+    };
+    auto finish_slot = [&](int s) {
+        const int n = __builtin_amdgcn_readlane(cnt, s);
+        const float fn = (float)n;
+        // means of the RAW coordinates from the sums of the pillar-local ones (exactly what the reference's
+        // f_cluster / f_center differences need: mean_x - centre_x = mean of x')
+        const float dxm = sx / fn, dym = sy / fn, mz = sz / fn;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            float k0 = bias[q];
+            k0 = fmaf(cxf, w[0][q], k0);
+            k0 = fmaf(cyf, w[1][q], k0);
+            k0 = fmaf(-dxm, w[F + 0][q], k0);
+            k0 = fmaf(-dym, w[F + 1][q], k0);
+            k0 = fmaf(-mz, w[F + 2][q], k0);
+            m[q] = fmaxf(k0 + m[q], 0.f);                                 // ReLU after the max (monotone)
+        }
+        if (n < T) {                                                     // zero-padded rows: ReLU(folded bias)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) m[q] = fmaxf(m[q], fmaxf(bias[q], 0.f));
+        }
+        if (p.feat_out != nullptr && ch_ok) {
+            const size_t row = (size_t)b * p.max_voxels + __builtin_amdgcn_readlane(pid, s);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) p.feat_out[row * C + ch0 + q] = m[q];
+        }
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { acc[q] += m[q]; m[q] = -3.0e38f; }
+    };
+    auto begin_slot = [&](int s) {
+        const int c = __builtin_amdgcn_readlane(slot_cell, s);
+        while (cur_cell < c) { write_cell(cur_cell); ++cur_cell; }
+        cxf = bcast(slot_cx, s);
+        cyf = bcast(slot_cy, s);
+        sx = sy = sz = 0.f;
+        cur_slot = s;
+    };
+    Batch cur = load_batch(0);
+    for (int base = 0; base < tot; base += 64) {
+        Batch nxt = cur;
+        if (base + 64 < tot) nxt = load_batch(base + 64);
+        const int nb = min(64, tot - base);
+        for (int jj = 0; jj < nb; ++jj) {
+            const int s = __builtin_amdgcn_readlane(cur.slot, jj);
+            if (s != cur_slot) {
+                if (cur_slot >= 0) finish_slot(cur_slot);
+                begin_slot(s);
+            }
+            const float fx = bcast(cur.x, jj) - cxf, fy = bcast(cur.y, jj) - cyf, fz = bcast(cur.z, jj);
+            const float fi = (F > 3) ? bcast(cur.i, jj) : 0.f;
+            sx += fx; sy += fy; sz += fz;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                float o = fx * wsx[q];
+                o = fmaf(fy, wsy[q], o);
+                o = fmaf(fz, wsz[q], o);
+                if (F > 3) o = fmaf(fi, w[F - 1][q], o);
+                m[q] = fmaxf(m[q], o);
+            }
+        }
+        cur = nxt;
+    }
+    if (cur_slot >= 0) finish_slot(cur_slot);
+    while (cur_cell < ncells) { write_cell(cur_cell); ++cur_cell; }
+}
+
+// PP_PFN_KERNEL=1 selects the first-generation kernel for the fused path (A/B timing)
+static bool pfn_first_generation() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PP_PFN_KERNEL");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 template <int CPL, int F>
 static void launch_pfn_t(const PfnParams& p, bool padded, hipStream_t s) {
     const int ncanvas = p.ny * p.nx;
     dim3 grid((ncanvas + 4 * PFN_CW - 1) / (4 * PFN_CW), p.batch);
-    if (padded)
+    if (padded) {
         hipLaunchKernelGGL((k_pfn_canvas<CPL, F, true>), grid, dim3(256), 0, s, p);
-    else
+    } else if (PFN2_CW * p.nz <= 64 && !pfn_first_generation()) {
+        dim3 grid2((ncanvas + 4 * PFN2_CW - 1) / (4 * PFN2_CW), p.batch);
+        hipLaunchKernelGGL((k_pfn_canvas2<CPL, F>), grid2, dim3(256), 0, s, p);
+    } else {
         hipLaunchKernelGGL((k_pfn_canvas<CPL, F, false>), grid, dim3(256), 0, s, p);
+    }
 }
 
 int launch_pfn(const PfnParams& p, bool padded, hipStream_t s) {

@@ -31,6 +31,8 @@
 
 #define VT 1024
 #define VWAVES 16
+#define VL_PPT 16               // points per thread on the LDS path
+#define VL_CAP (VT * VL_PPT)    // frames up to this many points take the LDS path
 
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     unsigned lane = threadIdx.x & 63u;
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
     __shared__ int s_break;
     __shared__ int s_tmp[VWAVES];
     __shared__ int s_hist[256 * VWAVES];
+    __shared__ unsigned s_sort[2 * VL_CAP];
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,6 +123,126 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
 
     if (tid == 0) { s_carry = 0; s_break = 0x7fffffff; }
     __syncthreads();
+
+    // ---- fast path: a frame of up to VL_CAP points is processed out of registers and LDS.  Every thread
+    // owns VL_PPT consecutive points (all of its loads are issued at once: one memory round trip per phase
+    // instead of one per 1024 points), pillar ids / compaction offsets come from one block-wide scan each,
+    // and the (pillar id, point index) pairs are packed into one 32-bit word and radix-sorted in LDS. ----
+    int ib = 1;
+    while ((1 << ib) < n) ++ib;                 // bits of a point index
+    if (n <= VL_CAP && npass * bits + ib <= 32) {
+        const int ppt = (n + VT - 1) / VT;      // <= VL_PPT
+        const int i0 = tid * ppt;
+        int c[VL_PPT];
+#pragma unroll
+        for (int k = 0; k < VL_PPT; ++k) c[k] = (k < ppt && i0 + k < n) ? fcell[i0 + k] : -1;
+        int f[VL_PPT];
+#pragma unroll
+        for (int k = 0; k < VL_PPT; ++k) f[k] = (c[k] >= 0) ? ffirst[c[k]] : -1;
+        unsigned flags = 0;
+#pragma unroll
+        for (int k = 0; k < VL_PPT; ++k) if (c[k] >= 0 && f[k] == i0 + k) flags |= 1u << k;
+        int totp;
+        const int basep = block_excl_scan(__popc(flags), s_tmp, totp);
+        {
+            int r = 0;
+#pragma unroll
+            for (int k = 0; k < VL_PPT; ++k)
+                if ((flags >> k) & 1u) {
+                    const int pid = basep + r++;
+                    if (pid < max_voxels) {
+                        fmap[c[k]] = pid;
+                        pillar_cell[(size_t)b * max_voxels + pid] = c[k];
+                    } else if (pid == max_voxels) {
+                        s_break = i0 + k;       // exactly one point has this prefix
+                    }
+                }
+        }
+        __syncthreads();                        // cell map of this frame + break point visible to the block
+        const int P = min(totp, max_voxels);
+        const int ibreak = s_break;
+        unsigned vmask = 0;
+#pragma unroll
+        for (int k = 0; k < VL_PPT; ++k) if (c[k] >= 0 && i0 + k < ibreak) vmask |= 1u << k;
+        int key[VL_PPT];
+#pragma unroll
+        for (int k = 0; k < VL_PPT; ++k) key[k] = ((vmask >> k) & 1u) ? fmap[c[k]] : 0;
+        int nv;
+        const int basev = block_excl_scan(__popc(vmask), s_tmp, nv);
+        {
+            int r = 0;
+#pragma unroll
+            for (int k = 0; k < VL_PPT; ++k)
+                if ((vmask >> k) & 1u) s_sort[basev + r++] = ((unsigned)key[k] << ib) | (unsigned)(i0 + k);
+        }
+        __syncthreads();
+        // stable LSD radix sort of the packed words by pillar id, LDS to LDS
+        unsigned* sk = s_sort;
+        unsigned* dk = s_sort + VL_CAP;
+        const int NB = 1 << bits;
+        const unsigned dmask = (unsigned)NB - 1u;
+        const int chunk = ((nv + VWAVES * 64 - 1) / (VWAVES * 64)) * 64;
+        const int wbeg = min(wave * chunk, nv), wend = min(wbeg + chunk, nv);
+        volatile int* vhist = s_hist;
+        for (int pass = 0; pass < npass; ++pass) {
+            const int shift = ib + pass * bits;
+            for (int e = tid; e < NB * VWAVES; e += VT) s_hist[e] = 0;
+            __syncthreads();
+            for (int t0 = wbeg; t0 < wend; t0 += 64) {
+                const int j = t0 + lane;
+                if (j < wend) atomicAdd(&s_hist[((sk[j] >> shift) & dmask) * VWAVES + wave], 1);
+            }
+            __syncthreads();
+            {
+                const int E = NB * VWAVES;
+                const int per = (E + VT - 1) / VT;
+                const int e0 = tid * per;
+                int local = 0;
+                for (int q = 0; q < per; ++q)
+                    if (e0 + q < E) local += s_hist[e0 + q];
+                int total;
+                int run = block_excl_scan(local, s_tmp, total);
+                for (int q = 0; q < per; ++q)
+                    if (e0 + q < E) { int t = s_hist[e0 + q]; s_hist[e0 + q] = run; run += t; }
+            }
+            __syncthreads();
+            for (int t0 = wbeg; t0 < wend; t0 += 64) {
+                const int j = t0 + lane;
+                const bool act = j < wend;
+                const unsigned v = act ? sk[j] : 0u;
+                const unsigned d = (v >> shift) & dmask;
+                unsigned long long peers = __ballot(act);
+                for (int bit = 0; bit < bits; ++bit) {
+                    const bool one = (d >> bit) & 1u;
+                    const unsigned long long bb = __ballot(act && one);
+                    peers &= one ? bb : ~bb;
+                }
+                if (act) {
+                    const int basepos = vhist[d * VWAVES + wave];
+                    dk[basepos + __popcll(peers & lt)] = v;
+                    if (lane == 63 - __clzll(peers)) vhist[d * VWAVES + wave] = basepos + __popcll(peers);
+                }
+            }
+            __syncthreads();
+            unsigned* t = sk; sk = dk; dk = t;
+        }
+        // sorted point indices + CSR row starts
+        unsigned* fin = ((npass & 1) ? idxB : idxA) + n0;     // the buffer the host reads (voxel_sort_passes)
+        int* ps = pillar_start + (size_t)b * (max_voxels + 1);
+        const unsigned imask = (1u << ib) - 1u;
+        for (int j = tid; j < nv; j += VT) {
+            const unsigned v = sk[j];
+            fin[j] = v & imask;
+            const unsigned k = v >> ib;
+            if (j == 0 || (sk[j - 1] >> ib) != k) ps[k] = j;
+        }
+        if (tid == 0) {
+            ps[P] = nv;
+            npillars[b] = P;
+            nvalid_out[b] = nv;
+        }
+        return;
+    }
 
     // ---- A: pillar ids in first-appearance order, break point ----
     for (int base = 0; base < n; base += VT) {
