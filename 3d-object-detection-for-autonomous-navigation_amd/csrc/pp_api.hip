@@ -240,7 +240,9 @@ std::vector<float> split_weights_bf16x3(const std::vector<float>& wt, int n_tota
 
 // ---- stage pipelines (all enqueue on e->stream) ----
 int run_voxelize(pp_engine* e, int batch, int max_n) {
-    {
+    const bool lds_first = voxel_first_in_lds(max_n, e->ncell, e->cfg.max_voxels);
+    int* d_first = lds_first ? nullptr : e->d_first;
+    if (!lds_first) {
         ProfScope ps(e, "memset_first");
         HIPCHK(e, hipMemsetAsync(e->d_first, 0x7f, (size_t)batch * e->ncell * sizeof(int), e->stream));
     }
@@ -250,11 +252,11 @@ int run_voxelize(pp_engine* e, int batch, int max_n) {
     }
     {
         ProfScope ps(e, "k_cell_first");
-        launch_cell_first(e->d_points, e->d_offsets, batch, max_n, e->F, e->geom, e->d_cell, e->d_first, e->stream);
+        launch_cell_first(e->d_points, e->d_offsets, batch, max_n, e->F, e->geom, e->d_cell, d_first, e->stream);
     }
     {
         ProfScope ps(e, "k_voxel_frame");
-        launch_voxel_frame(e->d_offsets, e->d_cell, e->d_first, e->d_cellmap, e->d_keyA, e->d_idxA, e->d_keyB,
+        launch_voxel_frame(e->d_offsets, e->d_cell, d_first, e->d_cellmap, e->d_keyA, e->d_idxA, e->d_keyB,
                            e->d_idxB, e->d_pstart, e->d_pcell, e->d_npillars, e->d_nvalid, batch, e->ncell,
                            e->cfg.max_voxels, e->stream);
     }

@@ -58,6 +58,7 @@ void launch_cell_first(const float* pts, const int* offsets, int batch, int max_
                        int* cell, int* first, hipStream_t s);
 // returns (through *sorted_in_b) nothing; the host derives the final buffer from voxel_sort_passes()
 int voxel_sort_passes(int max_voxels);
+bool voxel_first_in_lds(int max_n, int ncell, int max_voxels);   // pass first = NULL to both launchers below
 void launch_voxel_frame(const int* offsets, const int* cell, const int* first, int* cellmap, unsigned* keyA,
                         unsigned* idxA, unsigned* keyB, unsigned* idxB, int* pillar_start, int* pillar_cell,
                         int* npillars, int* nvalid, int batch, int ncell, int max_voxels, hipStream_t s);

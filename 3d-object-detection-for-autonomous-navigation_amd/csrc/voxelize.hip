@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_cell_first(const float* __restrict__ pt
     int lin = -1;
     if (ok) {
         lin = (c3[2] * g.grid[1] + c3[1]) * g.grid[0] + c3[0];  // (z, y, x)
-        atomicMin(&first[(size_t)b * g.ncell + lin], i);
+        if (first != nullptr) atomicMin(&first[(size_t)b * g.ncell + lin], i);   // NULL: k_voxel_frame finds the minima in LDS
     }
     cell[n0 + i] = lin;
 }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
     const int n0 = offsets[b];
     const int n = offsets[b + 1] - n0;
     const int* fcell = cell + n0;
-    const int* ffirst = first + (size_t)b * ncell;
+    const int* ffirst = (first != nullptr) ? first + (size_t)b * ncell : nullptr;
     int* fmap = cellmap + (size_t)b * ncell;
     unsigned* kA = keyA + n0;
     unsigned* vA = idxA + n0;
@@ -130,15 +130,29 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
     // and the (pillar id, point index) pairs are packed into one 32-bit word and radix-sorted in LDS. ----
     int ib = 1;
     while ((1 << ib) < n) ++ib;                 // bits of a point index
-    if (n <= VL_CAP && npass * bits + ib <= 32) {
+    if (n <= VL_CAP && npass * bits + ib <= 32 && (first != nullptr || ncell <= 2 * VL_CAP)) {
         const int ppt = (n + VT - 1) / VT;      // <= VL_PPT
         const int i0 = tid * ppt;
         int c[VL_PPT];
 #pragma unroll
         for (int k = 0; k < VL_PPT; ++k) c[k] = (k < ppt && i0 + k < n) ? fcell[i0 + k] : -1;
         int f[VL_PPT];
+        if (first != nullptr) {
 #pragma unroll
-        for (int k = 0; k < VL_PPT; ++k) f[k] = (c[k] >= 0) ? ffirst[c[k]] : -1;
+            for (int k = 0; k < VL_PPT; ++k) f[k] = (c[k] >= 0) ? ffirst[c[k]] : -1;
+        } else {
+            // first point index of every cell by LDS atomics (the sort buffers are not in use yet): no global
+            // atomics, whose same-address traffic on crowded cells serialises across the chip
+            int* s_first = reinterpret_cast<int*>(s_sort);
+            for (int e = tid; e < ncell; e += VT) s_first[e] = 0x7fffffff;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < VL_PPT; ++k) if (c[k] >= 0) atomicMin(&s_first[c[k]], i0 + k);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < VL_PPT; ++k) f[k] = (c[k] >= 0) ? s_first[c[k]] : -1;
+            __syncthreads();   // s_sort is written below
+        }
         unsigned flags = 0;
 #pragma unroll
         for (int k = 0; k < VL_PPT; ++k) if (c[k] >= 0 && f[k] == i0 + k) flags |= 1u << k;
@@ -413,6 +427,17 @@ __global__ __launch_bounds__(256) void k_build_cellmap(const int* __restrict__ c
     if (p >= P) return;
     const int b = coors4[p * 4 + 0], z = coors4[p * 4 + 1], y = coors4[p * 4 + 2], x = coors4[p * 4 + 3];
     cellmap[(size_t)b * ncell + ((size_t)z * ny + y) * nx + x] = (int)p;
+}
+
+// true when every frame of the batch takes k_voxel_frame's LDS path and its cell table fits LDS: the global
+// first-index table (memset + atomics) is then not needed at all
+bool voxel_first_in_lds(int max_n, int ncell, int max_voxels) {
+    int kb = 1, ib = 1;
+    while ((1 << kb) < max_voxels) ++kb;
+    while ((1 << ib) < max_n) ++ib;
+    const int npass = (kb + 7) / 8;
+    const int bits = (kb + npass - 1) / npass;
+    return max_n <= VL_CAP && ncell <= 2 * VL_CAP && npass * bits + ib <= 32;
 }
 
 void launch_cell_first(const float* pts, const int* offsets, int batch, int max_n, int F, const VoxGeom& g,
