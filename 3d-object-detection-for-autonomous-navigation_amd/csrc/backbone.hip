@@ -1286,6 +1286,9 @@ static int sep_u_nt(const LayerDesc& L, int batch) {
     if (L.cout % 64 != 0) return 32;
     if (L.cout % 128 != 0) return 64;
     const long long waves128 = ((long long)batch * L.out_h * L.out_w + 31) / 32 * (L.cout / 128);
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("PP_SEP_NT"); force = e ? atoi(e) : 0; }
+    if (force == 64 || force == 128) return force;
     return (waves128 * 2 < 5ll * g_num_cus * 4) ? 64 : 128;
 }
 
