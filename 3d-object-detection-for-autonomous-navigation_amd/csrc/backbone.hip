@@ -968,7 +968,7 @@ static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
 
 // Epilogue of one 128-pixel deconv tile (see k_deconv_u): so = this wave's [32][36] staging tile.
 template <int NT>
-__device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (&acc)[NT / 32], const float (&bias_r)[NT / 32],
+__device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (&acc)[NT / 32],
                                                      float hbias, int tile, int wave, int lane, int cbase, int delta,
                                                      const int* opix_tab, float* so, const float* sHW) {
     constexpr int NTILES = NT / 32, ESTR = 36;
@@ -1000,7 +1000,7 @@ __device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (
     for (int n = 0; n < NTILES; ++n) {
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[n][r] + bias_r[n], 0.f);
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[n][r], 0.f);   // bias is already in the accumulator
         if (heads) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) so[((r & 3) + 8 * (r >> 2) + 4 * h) * ESTR + r32] = v[r];
@@ -1023,7 +1023,17 @@ __device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (
                 hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, hacc, 0, 0, 0);
             }
         }
-        if (dst != nullptr) {
+        if (dst != nullptr && heads && !(a.dbg & 8192)) {
+            // the staged tile is already pixel-major: 16-byte rows of it go straight out (no register transposes)
+            const int erow = lane >> 3, ec4 = lane & 7;
+            float* dst2 = a.out + a.co_off + cbase + n * 32 + ec4 * 4;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float4 x = *reinterpret_cast<const float4*>(so + (erow + 8 * it) * ESTR + ec4 * 4);
+                if (full || pw + erow + 8 * it < a.M)
+                    *reinterpret_cast<float4*>(dst2 + (size_t)(opix_tab[wave * 32 + erow + 8 * it] + delta) * a.ld_out) = x;
+            }
+        } else if (dst != nullptr) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float x0 = v[4 * g + 0], x1 = v[4 * g + 1], x2 = v[4 * g + 2], x3 = v[4 * g + 3];
@@ -1156,14 +1166,14 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
     D_LOAD_B(0)
     int lb_kc = 1;                       // chunk index of the next weight tile to load
 
-    f32x16 acc[NTILES];
-#pragma unroll
-    for (int n = 0; n < NTILES; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     float bias_r[NTILES];
 #pragma unroll
     for (int n = 0; n < NTILES; ++n) bias_r[n] = a.bias[cbase + n * 32 + r32];
+    f32x16 acc[NTILES];   // accumulators start at the (BN-folded) bias: no add in the epilogue
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = bias_r[n];
     const float hbias = (a.head_mode == 1) ? a.head_bias[r32] : 0.f;
     int mm_tile = first, mm_kc = 0, mm_slot = 0;
     __syncthreads();                     // head weights / opix table visible
@@ -1200,10 +1210,10 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
             if (++lb_kc == nchunks) lb_kc = 0;                                                           \
         }                                                                                                \
         if (++mm_kc == nchunks) {                                                                        \
-            deconv_tile_epilogue<NT>(a, acc, bias_r, hbias, mm_tile, wave, lane, cbase, delta,       \
+            deconv_tile_epilogue<NT>(a, acc, hbias, mm_tile, wave, lane, cbase, delta,                   \
                                      s_opix[mm_slot], sStage + wave * 32 * ESTR, sHW);                   \
             _Pragma("unroll") for (int n = 0; n < NTILES; ++n)                                           \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;                          \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[n][r] = bias_r[n];                    \
             mm_kc = 0;                                                                                   \
             mm_tile += GL;                                                                               \
             mm_slot ^= 1;                                                                                \
@@ -1289,6 +1299,9 @@ static int sep_u_nt(const LayerDesc& L, int batch) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("PP_SEP_NT"); force = e ? atoi(e) : 0; }
     if (force == 64 || force == 128) return force;
+    // split-precision path: the depthwise (VALU) is the larger half of a chunk, so recomputing it per
+    // channel tile costs more than the thinner wave supply (measured: block3 at B=64 36 vs 40 us)
+    if (L.d_wt16 != nullptr && split_precision(0)) return 128;
     return (waves128 * 2 < 5ll * g_num_cus * 4) ? 64 : 128;
 }
 
