@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
     // A operand: this lane's 32 bytes of a chunk; byte offset of the tile's row (0 -> zero header when
     // the pixel is past the end)
     int ld_tile = first, ld_kc = 0;
-    unsigned avo;
+    unsigned avo = 0;
 #define D_TILE_AOFF(TILE)                                                                                \
     {                                                                                                    \
         const int pix_ = (TILE) * 128 + wave * 32 + r32;                                                 \
