@@ -33,6 +33,8 @@ __device__ __forceinline__ unsigned long long comp_key(float logit, unsigned a) 
 
 __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     __shared__ int s_hist[256];
+    __shared__ int s_cum[256];
+    __shared__ int s_wsum[4];
     __shared__ unsigned long long s_ckey[CCAP];   // compacted candidate keys (order irrelevant: keys are unique)
     __shared__ int s_ncand;
     __shared__ unsigned long long s_prefix;
@@ -75,11 +77,31 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     // ---- candidates -> LDS once (the head map is read a single time; the select passes run on LDS) ----
     if (tid == 0) { s_prefix = 0ull; s_need = KTOP; s_shift = 56; s_done = 0; s_cnt = 0; s_ncand = 0; }
     __syncthreads();
-    for (long long a = tid; a < A; a += PT) {
-        float lg;
-        if (!is_cand(a, lg)) continue;
-        const int pos = atomicAdd(&s_ncand, 1);
-        if (pos < CCAP) s_ckey[pos] = comp_key(lg, (unsigned)a);
+    // (8 anchors per thread at a time: the mask bytes, then the logits, are loaded together -- two memory
+    // round trips per 8192 anchors instead of two per 1024)
+    for (long long a0 = tid; a0 < A; a0 += 8 * PT) {
+        uint8_t mk[8];
+        float lgs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long a = a0 + (long long)k * PT;
+            mk[k] = (a < A) ? msk[a] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long a = a0 + (long long)k * PT;
+            lgs[k] = (mk[k] == 1) ? cls_of(a) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (mk[k] != 1) continue;
+            if (thr > 0.f) {
+                const float sc = 1.f / (1.f + expf(-lgs[k]));
+                if (!(sc >= thr)) continue;
+            }
+            const int pos = atomicAdd(&s_ncand, 1);
+            if (pos < CCAP) s_ckey[pos] = comp_key(lgs[k], (unsigned)(a0 + (long long)k * PT));
+        }
     }
     __syncthreads();
     const int ncand = s_ncand;
@@ -106,12 +128,38 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
             }
         }
         __syncthreads();
+        // digit of the need-th largest key: suffix sums over the 256 bins by 256 threads (bin 255 - tid)
+        if (tid < 256) {
+            const int lane_ = tid & 63, wv = tid >> 6;
+            const int hv = s_hist[255 - tid];
+            int incl = hv;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(incl, off);
+                if (lane_ >= off) incl += y;
+            }
+            if (lane_ == 63) s_wsum[wv] = incl;
+            s_cum[tid] = incl;   // within-wave inclusive sums; the wave offsets are added by thread 0 below
+        }
+        __syncthreads();
         if (tid == 0) {
             int need = s_need, cum = 0, digit = 0;
             bool found = false;
-            for (int d = 255; d >= 0; --d) {
-                if (cum + s_hist[d] >= need) { digit = d; need -= cum; found = true; break; }
-                cum += s_hist[d];
+            int woff = 0;
+            for (int wv = 0; wv < 4 && !found; ++wv) {
+                if (woff + s_wsum[wv] >= need) {   // the bin is inside this wave's 64: binary search on its inclusive sums
+                    int lo = 0, hi = 63;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (woff + s_cum[wv * 64 + mid] >= need) hi = mid; else lo = mid + 1;
+                    }
+                    const int t = wv * 64 + lo;
+                    digit = 255 - t;
+                    cum = woff + s_cum[t] - s_hist[digit];
+                    need -= cum;
+                    found = true;
+                }
+                woff += s_wsum[wv];
             }
             if (!found) {
                 // fewer candidates than requested (only possible in pass 0): take them all
