@@ -12,7 +12,13 @@ Pinning status (see DESIGN.md "Oracle"):
   * voxelise, anchors, anchor mask, box decode, corner/stand-up, NMS host sweep,
     lidar->camera: PINNED against outputs of the reference's own numpy code run
     in the build container (tools/gen_golden.py -> tests/golden/ref_*.npz).
-  * PFN / scatter / RPN (TensorFlow Keras layers), the numba-CUDA NMS kernel
+  * rotated-rectangle IoU of the AP evaluator (`oracle_rotate_iou_eval`, pp_oracle.c): PINNED bit
+    for bit against the reference's numba device functions executed as plain Python
+    (tools/gen_golden_eval.py -> tests/golden/ref_rotate_iou.npz, ref_kitti_eval.npz).
+  * the predict path's `+1` IoU (`iou_device`): formula PINNED to 1e-6 against the same kind of
+    run (ref_iou_device.npz); the last bits follow numba's float32+int64 -> float64 typing rule,
+    which a plain-Python run does not reproduce.
+  * PFN / scatter / RPN (TensorFlow Keras layers), the numba-CUDA `nms_kernel` indexing
     and `VoxelNet.predict` glue: PARITY UNPINNED -- TensorFlow 2.2 and numba
     0.51 are not installable here and the reference ships no tests or golden
     vectors; these parts are restated from the source (file:line cited per
