@@ -350,3 +350,22 @@ def test_error_behaviour(pp, engines):
     w["rpn/conv_box/kernel"] = w["rpn/conv_box/kernel"][..., :7]
     with pytest.raises(ValueError):
         eng.load_weights(w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"PP_GEMM_PREC": "f32"}, {"PP_GEMM_PREC": "f32", "PP_SEP_KERNEL": "ws"},
+                                 {"PP_PFN_KERNEL": "1"}])
+def test_fallback_kernel_generations_stay_in_parity(hip_lib, env):
+    """The earlier kernel generations are selectable at process start (fp32-MFMA instantiations, the
+    producer/consumer GEMM, the first PFN); one child process per selection runs the whole path on two
+    frames against the oracle (`__graft_entry__.smoke`), so the fallbacks do not rot."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child_env = dict(os.environ)
+    child_env.update(env)
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, env=child_env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "smoke OK" in r.stdout
