@@ -77,6 +77,10 @@ struct pp_engine {
     std::vector<int> h_offsets;
 
     int prof = 0;
+    // pp_detect_async as one hipGraph launch (captured on first use per (batch, max points per frame))
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_batch = -1, graph_max_n = -1;
+    int graph_state = 0;          // 0: try, -1: capture failed once (use plain launches)
     std::vector<hipEvent_t> events;
     std::vector<KTime> ktimes;
     int ev_used = 0;
@@ -570,10 +574,13 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
     return PP_OK;
 }
 
+static void graph_invalidate(pp_engine* e);
+
 int pp_destroy(pp_handle e) {
     if (!e) return PP_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    graph_invalidate(e);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->d_voxels) (void)hipFree(e->d_voxels);
     if (e->d_numpts) (void)hipFree(e->d_numpts);
@@ -602,6 +609,7 @@ int pp_set_weight(pp_handle e, const char* name, const float* data, const int64_
 }
 
 int pp_finalize_weights(pp_handle e) {
+    if (e) graph_invalidate(e);   // weight buffers are re-allocated below
     if (!e) return PP_ERR_ARG;
     (void)hipSetDevice(e->device);
     std::vector<float> sc, sh;
@@ -681,6 +689,7 @@ int pp_finalize_weights(pp_handle e) {
 }
 
 int pp_set_anchors(pp_handle e, const float* anchors, const int32_t* cells, int64_t num_anchors) {
+    if (e) graph_invalidate(e);
     if (!e) return PP_ERR_ARG;
     if (!anchors || !cells) return fail(e, PP_ERR_ARG, "pp_set_anchors: NULL argument");
     if (num_anchors != e->A) return fail(e, PP_ERR_SHAPE, "pp_set_anchors: got %lld anchors, config needs %lld", (long long)num_anchors, (long long)e->A);
@@ -730,14 +739,13 @@ int pp_set_calib(pp_handle e, const float* rect, const float* trv2c, int32_t bat
     return PP_OK;
 }
 
-int pp_detect_async(pp_handle e) {
-    if (!e) return PP_ERR_ARG;
-    if (!e->weights_ready) return fail(e, PP_ERR_STATE, "pp_detect_async: weights not finalised");
-    if (!e->anchors_ready) return fail(e, PP_ERR_STATE, "pp_detect_async: anchors not set");
-    if (e->cur_batch < 1) return fail(e, PP_ERR_STATE, "pp_detect_async: no frames uploaded");
-    (void)hipSetDevice(e->device);
-    const int B = e->cur_batch;
-    prof_reset(e);
+static void graph_invalidate(pp_engine* e) {
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+    e->graph_batch = e->graph_max_n = -1;
+}
+
+// the whole fused pipeline of one batch, enqueued on e->stream (plain launches or under stream capture)
+static int enqueue_detect(pp_engine* e, int B) {
     int st;
     if ((st = run_voxelize(e, B, e->cur_max_n))) return st;
     if ((st = run_pfn(e, B, false, nullptr))) return st;
@@ -747,6 +755,51 @@ int pp_detect_async(pp_handle e) {
     HIPCHK(e, hipMemcpyAsync(e->h_dets, e->d_dets, (size_t)B * e->cfg.nms_post_max_size * sizeof(pp_detection), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->h_ndets, e->d_ndets, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     return PP_OK;
+}
+
+static bool graphs_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* s = getenv("PP_NO_GRAPH");
+        v = (s && s[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+int pp_detect_async(pp_handle e) {
+    if (!e) return PP_ERR_ARG;
+    if (!e->weights_ready) return fail(e, PP_ERR_STATE, "pp_detect_async: weights not finalised");
+    if (!e->anchors_ready) return fail(e, PP_ERR_STATE, "pp_detect_async: anchors not set");
+    if (e->cur_batch < 1) return fail(e, PP_ERR_STATE, "pp_detect_async: no frames uploaded");
+    (void)hipSetDevice(e->device);
+    const int B = e->cur_batch;
+    prof_reset(e);
+    // ~35 launches per batch replay as ONE graph launch: every kernel argument is a device pointer or a
+    // per-(batch, max points) constant, so the captured graph is reusable until either changes (profiling
+    // needs the per-launch events and uses plain launches)
+    if (e->prof <= 0 && e->graph_state == 0 && graphs_enabled()) {
+        if (e->graph_exec == nullptr || e->graph_batch != B || e->graph_max_n != e->cur_max_n) {
+            graph_invalidate(e);
+            hipGraph_t g = nullptr;
+            bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            int st = ok ? enqueue_detect(e, B) : PP_ERR_HIP;
+            if (ok && hipStreamEndCapture(e->stream, &g) != hipSuccess) { ok = false; g = nullptr; }
+            if (ok && st == PP_OK && g != nullptr && hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                e->graph_batch = B;
+                e->graph_max_n = e->cur_max_n;
+            } else {
+                e->graph_exec = nullptr;
+                e->graph_state = -1;           // fall back to plain launches for the life of the handle
+                (void)hipGetLastError();
+            }
+            if (g) (void)hipGraphDestroy(g);
+        }
+        if (e->graph_exec != nullptr) {
+            HIPCHK(e, hipGraphLaunch(e->graph_exec, e->stream));
+            return PP_OK;
+        }
+    }
+    return enqueue_detect(e, B);
 }
 
 int pp_sync(pp_handle e) {
