@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--points", type=int, default=16384)
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight per GPU: each has its own engine handle (stream + workspaces), steps "
                          "alternate between them so the latency-bound front of one step (voxelise, PFN, NMS) "
                          "overlaps the MFMA-bound backbone of the other")

@@ -369,3 +369,36 @@ def test_fallback_kernel_generations_stay_in_parity(hip_lib, env):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "smoke OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_voxelise_size_boundaries_of_the_lds_path(pp, engines):
+    """Frames around the boundaries of k_voxel_frame's register / LDS path (<= 16384 points, 16 per thread)
+    and of its global-memory fallback, with a small max_voxels so the `break` falls inside the frame, as a
+    ragged batch through the fused path (per-frame coors / num_points from the intermediates)."""
+    rng = np.random.default_rng(99)
+    sizes = [1, 63, 1023, 1024, 1025, 4097, 16383, 16384, 16385, 20000]
+    cfg = pp.config.pedestrian_d435i_config(len(sizes))
+    cfg["model"]["second"]["voxel_generator"].update(max_number_of_points_per_voxel=7, max_number_of_voxels=900)
+    eng = engines("vox-bounds", cfg, max_batch=len(sizes), nmax=20480, weights_seed=7)
+    d = eng.d
+    frames = []
+    for n in sizes:
+        pts = np.stack([rng.uniform(-0.3, 6.8, n), rng.uniform(-2.8, 2.8, n), rng.uniform(-3.2, 3.2, n)], 1).astype(np.float32)
+        pts[rng.integers(0, n, max(1, n // 7))] = pts[rng.integers(0, n, max(1, n // 7))]   # duplicates
+        frames.append(pts)
+    rect, trv, _ = pp.synth.default_calib()
+    eng.detect(frames, np.stack([rect] * len(sizes)), np.stack([trv] * len(sizes)))
+    im = eng.intermediates()
+    for b, pts in enumerate(frames):
+        ve, ce, ne = c_oracle.points_to_voxel(pts, d.voxel_size, d.pc_range, d.max_points, d.max_voxels)
+        P = ce.shape[0]
+        assert im["n_pillars"][b] == P, (sizes[b], im["n_pillars"][b], P)
+        assert np.array_equal(im["coors"][b, :P], ce), sizes[b]
+        assert np.array_equal(im["num_points"][b, :P], ne), sizes[b]
+    # and one at a time through the padded compat entry point (both paths again, different batch shape)
+    for n in (1024, 16384, 16385):
+        pts = frames[sizes.index(n)]
+        v, c, k = eng.points_to_voxel(pts)
+        ve, ce, ne = c_oracle.points_to_voxel(pts, d.voxel_size, d.pc_range, d.max_points, d.max_voxels)
+        assert np.array_equal(c, ce) and np.array_equal(k, ne) and np.array_equal(v, ve)
