@@ -966,90 +966,71 @@ static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
         hipLaunchKernelGGL((k_sep_u<NT, S, WPS, 0>), grid, dim3(256), 0, s, a, ntiles);
 }
 
-// Epilogue of one 128-pixel deconv tile (see k_deconv_u): so = this wave's [32][36] staging tile.
+// Epilogue of one 128-pixel deconv tile (see k_deconv_u).  Accumulator layout (operands swapped in the
+// MFMAs): lane & 31 = pixel of the wave's 32, register r of tile n = channel n*32 + DCH(r, h).
+#define DCH(R, H) (((R) & 3) + 8 * ((R) >> 2) + 4 * (H))
 template <int NT>
 __device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (&acc)[NT / 32],
-                                                     float hbias, int tile, int wave, int lane, int cbase, int delta,
-                                                     const int* opix_tab, float* so, const float* sHW) {
-    constexpr int NTILES = NT / 32, ESTR = 36;
+                                                     int tile, int wave, int lane, int cbase, int delta,
+                                                     const int* opix_tab, const float* sHW, const float* s_hbias) {
+    constexpr int NTILES = NT / 32;
     const int h = lane >> 5, r32 = lane & 31;
-    const int pw = tile * 128 + wave * 32;
-    if ((a.dbg & 4) || pw >= a.M) return;
-    const bool full = pw + 32 <= a.M;   // wave-uniform
-    const int qi = lane & 3, qj = r32 >> 2;
-    int orow[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) orow[g] = opix_tab[wave * 32 + 8 * g + 4 * h + qi] + delta;
+    const int pix = tile * 128 + wave * 32 + r32;
+    if ((a.dbg & 4) || tile * 128 + wave * 32 >= a.M) return;
+    const bool ok = pix < a.M;
+    const size_t orow = (size_t)(opix_tab[wave * 32 + r32] + delta);   // this lane's output pixel
     const bool heads = a.head_mode != 0;
-    float hold[16];
+    // head map row of this pixel: this lane owns columns 4h + {0..3, 8..11, 16..19, 24..27} (4 x 16 bytes);
+    // the earlier branches' partial sums (mode 2) are fetched now and used at the end
+    float4 hold[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hold[r] = 0.f;
-    if (a.head_mode == 2) {   // partial sums of the earlier branches: loads issued now, used at the end
+    for (int g = 0; g < 4; ++g) hold[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* hrow = a.head + orow * PP_HEAD_COLS + 4 * h;
+    if (a.head_mode == 2 && ok) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (full || pw + row < a.M)
-                hold[r] = a.head[(size_t)(opix_tab[wave * 32 + row] + delta) * PP_HEAD_COLS + r32];
-        }
+        for (int g = 0; g < 4; ++g) hold[g] = *reinterpret_cast<const float4*>(hrow + 8 * g);
     }
     f32x16 hacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
-    float* dst = (a.out != nullptr) ? a.out + a.co_off + cbase + qj * 4 : nullptr;
+    for (int r = 0; r < 16; ++r) hacc[r] = (a.head_mode == 1) ? s_hbias[DCH(r, h)] : 0.f;
+    float* dst = (a.out != nullptr) ? a.out + orow * a.ld_out + a.co_off + cbase + 4 * h : nullptr;
 #pragma unroll
     for (int n = 0; n < NTILES; ++n) {
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[n][r], 0.f);   // bias is already in the accumulator
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[n][r], 0.f);   // the folded bias is the accumulator's initial value
         if (heads) {
+            // the activated values are already a B operand (k = channel, column = pixel) up to a fixed
+            // permutation of k, which the head kernels carry as well (pp_api.hip: head_k_permutation)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) so[((r & 3) + 8 * (r >> 2) + 4 * h) * ESTR + r32] = v[r];
-#pragma unroll
-            for (int g16 = 0; g16 < 2; ++g16) {
-                const float4 x0 = *reinterpret_cast<const float4*>(so + r32 * ESTR + g16 * 16 + h * 8);
-                const float4 x1 = *reinterpret_cast<const float4*>(so + r32 * ESTR + g16 * 16 + h * 8 + 4);
-                const float av[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                bf16x8 ah, am, al;
-                split_bf16x3(av, ah, am, al);
-                const float* hB = sHW + ((n * 2 + g16) * 3 * 32 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hB);
-                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(hB + 32 * 8);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(hB + 2 * 32 * 8);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, hacc, 0, 0, 0);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, hacc, 0, 0, 0);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, hacc, 0, 0, 0);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, hacc, 0, 0, 0);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, hacc, 0, 0, 0);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, hacc, 0, 0, 0);
+            for (int g = 0; g < 2; ++g) {
+                const float av[8] = {v[8 * g], v[8 * g + 1], v[8 * g + 2], v[8 * g + 3],
+                                     v[8 * g + 4], v[8 * g + 5], v[8 * g + 6], v[8 * g + 7]};
+                bf16x8 xh, xm, xl;
+                split_bf16x3(av, xh, xm, xl);
+                const float* hW = sHW + ((n * 2 + g) * 3 * 32 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(hW);
+                const bf16x8 wm = *reinterpret_cast<const bf16x8*>(hW + 32 * 8);
+                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(hW + 2 * 32 * 8);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, hacc, 0, 0, 0);
             }
         }
-        if (dst != nullptr && heads && !(a.dbg & 8192)) {
-            // the staged tile is already pixel-major: 16-byte rows of it go straight out (no register transposes)
-            const int erow = lane >> 3, ec4 = lane & 7;
-            float* dst2 = a.out + a.co_off + cbase + n * 32 + ec4 * 4;
+        if (dst != nullptr && ok) {   // concat slice (only when the heads are not fused): 4 consecutive channels per store
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const float4 x = *reinterpret_cast<const float4*>(so + (erow + 8 * it) * ESTR + ec4 * 4);
-                if (full || pw + erow + 8 * it < a.M)
-                    *reinterpret_cast<float4*>(dst2 + (size_t)(opix_tab[wave * 32 + erow + 8 * it] + delta) * a.ld_out) = x;
-            }
-        } else if (dst != nullptr) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float x0 = v[4 * g + 0], x1 = v[4 * g + 1], x2 = v[4 * g + 2], x3 = v[4 * g + 3];
-                quad_transpose4(x0, x1, x2, x3, lane);
-                if (full || pw + 8 * g + 4 * h + qi < a.M)
-                    *reinterpret_cast<float4*>(dst + (size_t)orow[g] * a.ld_out + n * 32) = make_float4(x0, x1, x2, x3);
-            }
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(dst + n * 32 + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
         }
     }
-    if (heads) {
+    if (heads && ok) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (full || pw + row < a.M)
-                a.head[(size_t)(opix_tab[wave * 32 + row] + delta) * PP_HEAD_COLS + r32] = hacc[r] + hbias + hold[r];
-        }
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(hrow + 8 * g) = make_float4(hacc[4 * g] + hold[g].x, hacc[4 * g + 1] + hold[g].y,
+                                                                  hacc[4 * g + 2] + hold[g].z, hacc[4 * g + 3] + hold[g].w);
     }
 }
 
@@ -1057,18 +1038,20 @@ __device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (
 // Uniform-wave Conv2DTranspose (kernel == stride) + BN + ReLU [+ fused SSD heads], split-precision bf16.
 //
 // Same skeleton as k_sep_u (persistent 4-wave workgroups, wave w owns input pixels 32w..32w+31 of a
-// 128-pixel tile, one barrier per 16-channel K-chunk for the shared weight tile), but the A operand
-// needs no LDS at all: lane (r, h) of the MFMA layout owns pixel r, channels 8h..8h+7 of the chunk,
-// i.e. 32 contiguous bytes of the input row, loaded straight into registers two K-chunks ahead (two
-// register sets alternate; every layer has an even number of chunks), split into three bf16 pieces and
-// multiplied.  blockIdx.y selects NT of the k*k*cout GEMM columns (one tap when NT == cout).
-// Epilogue: bias + ReLU, 4 x 4 DPP transposes, 16-byte stores into the pixel-shuffled position of the
-// concat buffer (output pixel index per input pixel from a small double-buffered LDS table that is
-// filled one tile ahead).  With fused heads the activated 32 x 32 blocks are turned around through a
-// per-wave LDS staging tile into A operands, split, and multiplied with this branch's slice of the
-// head kernels (three bf16 pieces, resident in LDS for the whole launch); the 32-column partial result
-// is added to the head map by a race-free read-modify-write (the three deconv launches run in stream
-// order and a (pixel, column) pair is touched by exactly one wave per launch).
+// 128-pixel tile, one barrier per 16-channel K-chunk for the shared weight tile), but the input operand
+// needs no LDS at all: lane (r, h) owns pixel r, channels 8h..8h+7 of the chunk, i.e. 32 contiguous
+// bytes of the input row, loaded straight into registers two K-chunks ahead (two register sets
+// alternate; every layer has an even number of chunks), split into three bf16 pieces and multiplied.
+// The MFMAs take the WEIGHT fragment as the A operand and the input fragment as B, so the accumulator
+// holds out^T: lane = pixel, registers = 16 channels of that pixel.  That layout is, up to a fixed
+// permutation of k, the B operand of the head GEMM head^T[32 x px] = Wh^T[32 x ch] . act^T[ch x px]:
+// the fused heads run straight out of the accumulator registers (ReLU, split, 6 MFMAs per 16 channels)
+// with no transposition through LDS, and every lane ends up with 4 x 4 consecutive head columns of its
+// own pixel, which it adds to the head map with four 16-byte read-modify-writes (race-free: the three
+// deconv launches run in stream order and a pixel's row is touched by one half-wave pair per launch).
+// blockIdx.y selects NT of the k*k*cout GEMM columns (one tap when NT == cout).  The folded bias is the
+// accumulators' initial value (per-channel, from LDS).  Output pixel index per input pixel comes from a
+// small double-buffered LDS table filled one tile ahead.
 template <int NT, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
     constexpr int KCH = 16;
@@ -1076,11 +1059,11 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
     constexpr int SB = 3 * NT * 8;                       // one weight buffer: [3 pieces][NT][8 floats]
     constexpr int NBI = NT * 6;                          // 16-byte weight items per chunk
     constexpr int NB4 = (NBI + 255) / 256;
-    constexpr int ESTR = 36;                             // head staging row stride (floats)
     constexpr int SHW = (NT / 16) * 3 * 32 * 8;          // head weights: [NT/16][3][32 cols][8 floats]
     __shared__ __attribute__((aligned(16))) float sB[2 * SB];
     __shared__ __attribute__((aligned(16))) float sHW[SHW];
-    __shared__ __attribute__((aligned(16))) float sStage[4 * 32 * ESTR];
+    __shared__ float s_bias[NT];
+    __shared__ float s_hbias[PP_HEAD_COLS];
     __shared__ int s_opix[2][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, r32 = lane & 31;
@@ -1110,9 +1093,11 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
         s_opix[SLOT][tid] = (b_ * a.px_h * a.k + y_ * a.k) * (a.px_w * a.k) + x_ * a.k; \
     }
     D_FILL_OPIX(first, 0)
+    if (tid < NT) s_bias[tid] = a.bias[cbase + tid];
     if (heads) {   // this branch's head-kernel slice, three bf16 pieces, into LDS once
         for (int e = tid; e < SHW / 4; e += 256)   // 16-byte halves swapped on odd groups of 8 columns (bank conflicts)
             reinterpret_cast<float4*>(sHW)[e ^ ((e >> 4) & 1)] = reinterpret_cast<const float4*>(a.head_wt16)[e];
+        if (tid < PP_HEAD_COLS) s_hbias[tid] = a.head_bias[tid];
     }
 
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
@@ -1143,7 +1128,7 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
         if (NB4 > 1 && (NBI >= 512 || tid + 256 < NBI)) *reinterpret_cast<float4*>(sB + (BUF) * SB + bdst[NB4 > 1 ? 1 : 0]) = rb1;  \
         if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) *reinterpret_cast<float4*>(sB + (BUF) * SB + bdst[NB4 > 2 ? 2 : 0]) = rb2;  \
     }
-    // A operand: this lane's 32 bytes of a chunk; byte offset of the tile's row (0 -> zero header when
+    // input operand: this lane's 32 bytes of a chunk; byte offset of the tile's row (0 -> zero header when
     // the pixel is past the end)
     int ld_tile = first, ld_kc = 0;
     unsigned avo = 0;
@@ -1160,29 +1145,25 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
         R1 = buf_load16(rs_in, avo + 16u, so_);                                                          \
         if (++ld_kc == nchunks) { ld_kc = 0; ld_tile += GL; }                                            \
     }
-    float4 ra0, ra1, rc0, rc1;           // raw A of even / odd stream positions
+    float4 ra0, ra1, rc0, rc1;           // raw input of even / odd stream positions
     D_LOAD_A(ra0, ra1)                   // position 0
     D_LOAD_A(rc0, rc1)                   // position 1 (total >= 2)
     D_LOAD_B(0)
     int lb_kc = 1;                       // chunk index of the next weight tile to load
 
-    float bias_r[NTILES];
-#pragma unroll
-    for (int n = 0; n < NTILES; ++n) bias_r[n] = a.bias[cbase + n * 32 + r32];
-    f32x16 acc[NTILES];   // accumulators start at the (BN-folded) bias: no add in the epilogue
-#pragma unroll
-    for (int n = 0; n < NTILES; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = bias_r[n];
-    const float hbias = (a.head_mode == 1) ? a.head_bias[r32] : 0.f;
     int mm_tile = first, mm_kc = 0, mm_slot = 0;
-    __syncthreads();                     // head weights / opix table visible
+    __syncthreads();                     // bias / head weights / opix table visible
+    f32x16 acc[NTILES];                  // accumulators start at the (BN-folded) bias of their channel
+#define D_INIT_ACC()                                                                                     \
+    _Pragma("unroll") for (int n = 0; n < NTILES; ++n)                                                   \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[n][r] = s_bias[n * 32 + DCH(r, h)];
+    D_INIT_ACC()
     D_STORE_B(0)
     D_LOAD_B(lb_kc)
     if (++lb_kc == nchunks) lb_kc = 0;
     __syncthreads();
 
-    // one stream position: multiply chunk i (raw A in RA0/RA1), prefetch position i+2 into the same registers
+    // one stream position: multiply chunk i (raw input in RA0/RA1), prefetch position i+2 into the same registers
 #define D_STEP(I, RA0, RA1)                                                                              \
     {                                                                                                    \
         const int i_ = (I);                                                                              \
@@ -1196,12 +1177,12 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
                 const bf16x8 bh_ = *reinterpret_cast<const bf16x8*>(cB_ + n * 32 * 8);                   \
                 const bf16x8 bm_ = *reinterpret_cast<const bf16x8*>(cB_ + NT * 8 + n * 32 * 8);          \
                 const bf16x8 bl_ = *reinterpret_cast<const bf16x8*>(cB_ + 2 * NT * 8 + n * 32 * 8);      \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_, acc[n], 0, 0, 0);             \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_, acc[n], 0, 0, 0);             \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am_, bm_, acc[n], 0, 0, 0);             \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am_, bh_, acc[n], 0, 0, 0);             \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bm_, acc[n], 0, 0, 0);             \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_, al_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl_, ah_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm_, am_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_, am_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm_, ah_, acc[n], 0, 0, 0);             \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_, ah_, acc[n], 0, 0, 0);             \
             }                                                                                            \
         }                                                                                                \
         if (i_ + 1 < total) {   /* weight tile of position i+1 -> LDS, loads of position i+2 */         \
@@ -1210,10 +1191,8 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
             if (++lb_kc == nchunks) lb_kc = 0;                                                           \
         }                                                                                                \
         if (++mm_kc == nchunks) {                                                                        \
-            deconv_tile_epilogue<NT>(a, acc, hbias, mm_tile, wave, lane, cbase, delta,                   \
-                                     s_opix[mm_slot], sStage + wave * 32 * ESTR, sHW);                   \
-            _Pragma("unroll") for (int n = 0; n < NTILES; ++n)                                           \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[n][r] = bias_r[n];                    \
+            deconv_tile_epilogue<NT>(a, acc, mm_tile, wave, lane, cbase, delta, s_opix[mm_slot], sHW, s_hbias);  \
+            D_INIT_ACC()                                                                                 \
             mm_kc = 0;                                                                                   \
             mm_tile += GL;                                                                               \
             mm_slot ^= 1;                                                                                \
@@ -1227,6 +1206,7 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
         D_STEP(i + 1, rc0, rc1)
     }
 #undef D_STEP
+#undef D_INIT_ACC
 #undef D_LOAD_A
 #undef D_TILE_AOFF
 #undef D_STORE_B

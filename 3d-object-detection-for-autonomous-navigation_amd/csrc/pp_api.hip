@@ -675,7 +675,19 @@ int pp_finalize_weights(pp_handle e) {
                 for (int o = 0; o < PP_HEAD_COLS; ++o)
                     for (int c = 0; c < L.cout; ++c) hw[(size_t)o * L.cout + c] = headw[(size_t)o * e->CC + L.co_off + c];
                 st = upload(e, &L.d_head_wt, hw); if (st) return st;
-                if (L.cout % 16 == 0) { st = upload(e, &L.d_head_wt16, split_weights_bf16x3(hw, PP_HEAD_COLS, L.cout)); if (st) return st; }
+                if (L.cout % 32 == 0) {
+                    // k_deconv_u feeds the head GEMM from its accumulator registers: slot (h, j) of 16-channel group
+                    // (n, g) holds channel n*32 + (j&3) + 8*(2g + (j>>2)) + 4h (the 32x32 MFMA result layout); the
+                    // head kernels get the same order of k
+                    std::vector<float> hwp(hw.size());
+                    for (int o = 0; o < PP_HEAD_COLS; ++o)
+                        for (int c = 0; c < L.cout; ++c) {
+                            const int n = c / 32, g = (c % 32) / 16, sl = c % 16, hh = sl / 8, j = sl % 8;
+                            const int src = n * 32 + (j & 3) + 8 * (2 * g + (j >> 2)) + 4 * hh;
+                            hwp[(size_t)o * L.cout + c] = hw[(size_t)o * L.cout + src];
+                        }
+                    st = upload(e, &L.d_head_wt16, split_weights_bf16x3(hwp, PP_HEAD_COLS, L.cout)); if (st) return st;
+                }
                 st = upload(e, &L.d_head_bias, headb); if (st) return st;
             }
             ++bi; li = 0;
