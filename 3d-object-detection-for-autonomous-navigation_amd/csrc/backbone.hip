@@ -982,17 +982,20 @@ __device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (
     const bool heads = a.head_mode != 0;
     // head map row of this pixel: this lane owns columns 4h + {0..3, 8..11, 16..19, 24..27} (4 x 16 bytes);
     // the earlier branches' partial sums (mode 2) are fetched now and used at the end
-    float4 hold[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) hold[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the head accumulator starts at the head bias (first branch) or at the partial sums the earlier branches
+    // left in the head map (its 16 registers are exactly this lane's 4 x 16 bytes of the row)
     float* hrow = a.head + orow * PP_HEAD_COLS + 4 * h;
+    f32x16 hacc;
     if (a.head_mode == 2 && ok) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) hold[g] = *reinterpret_cast<const float4*>(hrow + 8 * g);
-    }
-    f32x16 hacc;
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = *reinterpret_cast<const float4*>(hrow + 8 * g);
+            hacc[4 * g] = t.x; hacc[4 * g + 1] = t.y; hacc[4 * g + 2] = t.z; hacc[4 * g + 3] = t.w;
+        }
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hacc[r] = (a.head_mode == 1) ? s_hbias[DCH(r, h)] : 0.f;
+        for (int r = 0; r < 16; ++r) hacc[r] = (a.head_mode == 1) ? s_hbias[DCH(r, h)] : 0.f;
+    }
     float* dst = (a.out != nullptr) ? a.out + orow * a.ld_out + a.co_off + cbase + 4 * h : nullptr;
 #pragma unroll
     for (int n = 0; n < NTILES; ++n) {
@@ -1029,8 +1032,7 @@ __device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (
     if (heads && ok) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(hrow + 8 * g) = make_float4(hacc[4 * g] + hold[g].x, hacc[4 * g + 1] + hold[g].y,
-                                                                  hacc[4 * g + 2] + hold[g].z, hacc[4 * g + 3] + hold[g].w);
+            *reinterpret_cast<float4*>(hrow + 8 * g) = make_float4(hacc[4 * g], hacc[4 * g + 1], hacc[4 * g + 2], hacc[4 * g + 3]);
     }
 }
 
@@ -1185,11 +1187,7 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_, ah_, acc[n], 0, 0, 0);             \
             }                                                                                            \
         }                                                                                                \
-        if (i_ + 1 < total) {   /* weight tile of position i+1 -> LDS, loads of position i+2 */         \
-            D_STORE_B((i_ + 1) & 1)                                                                      \
-            if (i_ + 2 < total) D_LOAD_B(lb_kc)                                                          \
-            if (++lb_kc == nchunks) lb_kc = 0;                                                           \
-        }                                                                                                \
+        if (i_ + 1 < total) D_STORE_B((i_ + 1) & 1)   /* weight tile of position i+1 -> LDS */          \
         if (++mm_kc == nchunks) {                                                                        \
             deconv_tile_epilogue<NT>(a, acc, mm_tile, wave, lane, cbase, delta, s_opix[mm_slot], sHW, s_hbias);  \
             D_INIT_ACC()                                                                                 \
@@ -1198,6 +1196,10 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
             mm_slot ^= 1;                                                                                \
         } else if (mm_kc == 1 && mm_tile + GL < tend) {                                                  \
             D_FILL_OPIX(mm_tile + GL, mm_slot ^ 1)   /* table of the next tile, one tile ahead */        \
+        }                                                                                                \
+        if (i_ + 1 < total) {   /* weight loads of position i+2 (after the epilogue: not live across it) */ \
+            if (i_ + 2 < total) D_LOAD_B(lb_kc)                                                          \
+            if (++lb_kc == nchunks) lb_kc = 0;                                                           \
         }                                                                                                \
         __syncthreads();                                                                                 \
     }
@@ -1216,7 +1218,7 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
 
 template <int NT>
 static void launch_deconv_u(const GemmArgs& a, int n_total, hipStream_t s) {
-    constexpr int WPS = 2;
+    constexpr int WPS = 3;
     const int ntiles = (a.M + 127) / 128;
     const int ny = n_total / NT;
     int slots = (g_num_cus * WPS) / ny;
@@ -1327,7 +1329,7 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
         else wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 2 : (unt == 64 ? 3 : 4));
         snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d,%d>", unt, L.stride, wps, bf ? 1 : 0);
     } else if (deconv_uniform(L, 0)) {
-        snprintf(buf, sizeof(buf), "k_deconv_u<%d,2>", nt);
+        snprintf(buf, sizeof(buf), "k_deconv_u<%d,3>", nt);
     } else if (use_ws(L)) {
         const int pxb = ws_small_tile(layer_rows(L, batch), L.n_total, nt) ? 64 : 128;
         snprintf(buf, sizeof(buf), "k_gemm_ws<%d,%d,%d,%d>", nt, mode, mode == 0 ? L.stride : 1, pxb);
