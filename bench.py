@@ -55,9 +55,10 @@ def layer_bytes(d, batch, heads_fused=False):
             out[f"block{b + 1}.{j}"] = 4.0 * batch * (h * w * cin + ho * wo * cout)
             h, w, cin = ho, wo, cout
         k = d.upsample_strides[b]
-        out[f"deconv{b + 1}"] = 4.0 * batch * (h * w * cin + h * k * w * k * d.num_upsample_filters[b])
-        if heads_fused:
-            out[f"deconv{b + 1}"] += 4.0 * batch * d.head_h * d.head_w * 32 * (1 if b == 0 else 2)
+        if heads_fused:   # the concat slice is never written: input map + the 32-column head map (write, or read + write)
+            out[f"deconv{b + 1}"] = 4.0 * batch * (h * w * cin + d.head_h * d.head_w * 32 * (1 if b == 0 else 2))
+        else:
+            out[f"deconv{b + 1}"] = 4.0 * batch * (h * w * cin + h * k * w * k * d.num_upsample_filters[b])
     if not heads_fused:
         out["heads"] = 4.0 * batch * d.head_h * d.head_w * (d.concat_channels + 32)
     return out
