@@ -78,8 +78,9 @@ struct pp_engine {
 
     int prof = 0;
     // pp_detect_async as one hipGraph launch (captured on first use per (batch, max points per frame))
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_batch = -1, graph_max_n = -1;
+    struct GraphSlot { hipGraphExec_t exec = nullptr; int batch = -1, bucket = -1; unsigned long long used = 0; };
+    GraphSlot graphs[4];          // small LRU keyed by (batch, point-count bucket)
+    unsigned long long graph_tick = 0;
     int graph_state = 0;          // 0: try, -1: capture failed once (use plain launches)
     std::vector<hipEvent_t> events;
     std::vector<KTime> ktimes;
@@ -752,14 +753,26 @@ int pp_set_calib(pp_handle e, const float* rect, const float* trv2c, int32_t bat
 }
 
 static void graph_invalidate(pp_engine* e) {
-    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-    e->graph_batch = e->graph_max_n = -1;
+    for (auto& g : e->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        g = pp_engine::GraphSlot();
+    }
+}
+
+// The only launch parameters that depend on the frames' point counts are k_cell_first's grid and the
+// LDS-vs-global choice of the voxeliser, both functions of max(points per frame): a graph is keyed by that
+// maximum rounded up to 4096 (the kernels bound-check every frame against its own count), so batches of
+// similar size share one graph.
+static int graph_bucket(const pp_engine* e, int max_n) {
+    int b = ((max_n + 4095) / 4096) * 4096;
+    if (b < 4096) b = 4096;
+    return b < e->cfg.max_points_per_frame ? b : e->cfg.max_points_per_frame;
 }
 
 // the whole fused pipeline of one batch, enqueued on e->stream (plain launches or under stream capture)
-static int enqueue_detect(pp_engine* e, int B) {
+static int enqueue_detect(pp_engine* e, int B, int max_n) {
     int st;
-    if ((st = run_voxelize(e, B, e->cur_max_n))) return st;
+    if ((st = run_voxelize(e, B, max_n))) return st;
     if ((st = run_pfn(e, B, false, nullptr))) return st;
     if ((st = run_anchor_mask(e, B))) return st;
     if ((st = run_backbone(e, B))) return st;
@@ -790,28 +803,38 @@ int pp_detect_async(pp_handle e) {
     // per-(batch, max points) constant, so the captured graph is reusable until either changes (profiling
     // needs the per-launch events and uses plain launches)
     if (e->prof <= 0 && e->graph_state == 0 && graphs_enabled()) {
-        if (e->graph_exec == nullptr || e->graph_batch != B || e->graph_max_n != e->cur_max_n) {
-            graph_invalidate(e);
+        const int bucket = graph_bucket(e, e->cur_max_n);
+        pp_engine::GraphSlot* slot = nullptr;
+        pp_engine::GraphSlot* lru = &e->graphs[0];
+        for (auto& g : e->graphs) {
+            if (g.exec && g.batch == B && g.bucket == bucket) slot = &g;
+            if (g.used < lru->used) lru = &g;
+        }
+        if (slot == nullptr) {
+            slot = lru;
+            if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
+            *slot = pp_engine::GraphSlot();
             hipGraph_t g = nullptr;
             bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            int st = ok ? enqueue_detect(e, B) : PP_ERR_HIP;
+            int st = ok ? enqueue_detect(e, B, bucket) : PP_ERR_HIP;
             if (ok && hipStreamEndCapture(e->stream, &g) != hipSuccess) { ok = false; g = nullptr; }
-            if (ok && st == PP_OK && g != nullptr && hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
-                e->graph_batch = B;
-                e->graph_max_n = e->cur_max_n;
+            if (ok && st == PP_OK && g != nullptr && hipGraphInstantiate(&slot->exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                slot->batch = B;
+                slot->bucket = bucket;
             } else {
-                e->graph_exec = nullptr;
+                slot->exec = nullptr;
                 e->graph_state = -1;           // fall back to plain launches for the life of the handle
                 (void)hipGetLastError();
             }
             if (g) (void)hipGraphDestroy(g);
         }
-        if (e->graph_exec != nullptr) {
-            HIPCHK(e, hipGraphLaunch(e->graph_exec, e->stream));
+        if (slot->exec != nullptr) {
+            slot->used = ++e->graph_tick;
+            HIPCHK(e, hipGraphLaunch(slot->exec, e->stream));
             return PP_OK;
         }
     }
-    return enqueue_detect(e, B);
+    return enqueue_detect(e, B, e->cur_max_n);
 }
 
 int pp_sync(pp_handle e) {

@@ -402,3 +402,26 @@ def test_voxelise_size_boundaries_of_the_lds_path(pp, engines):
         v, c, k = eng.points_to_voxel(pts)
         ve, ce, ne = c_oracle.points_to_voxel(pts, d.voxel_size, d.pc_range, d.max_points, d.max_voxels)
         assert np.array_equal(c, ce) and np.array_equal(k, ne) and np.array_equal(v, ve)
+
+
+@pytest.mark.gpu
+def test_graph_cache_across_changing_batches(pp, engines):
+    """pp_detect_async replays cached hipGraphs keyed by (batch, point-count bucket): batches of changing
+    size and point counts (more distinct keys than cache slots, with repeats) must keep matching the plain
+    launches of a profiling run, which never uses a graph."""
+    cfg = pp.config.pedestrian_d435i_config(4)
+    eng = engines("graph-cache", cfg, max_batch=4, nmax=20480, weights_seed=7)
+    rect, trv, _ = pp.synth.default_calib()
+    shapes = [(4, 3000), (2, 3000), (4, 9000), (1, 17000), (3, 12000), (4, 20000), (4, 3000), (2, 3000), (1, 17000)]
+    for k, (nb, npts) in enumerate(shapes):
+        frames = [pp.synth.d435i_cloud(500 + 10 * k + i, npts - 37 * i) for i in range(nb)]
+        r, t = np.stack([rect] * nb), np.stack([trv] * nb)
+        dets, n = eng.detect(frames, r, t)                      # graph path
+        eng.set_profiling(True)
+        dets2, n2 = eng.detect(frames, r, t)                    # plain launches
+        eng.set_profiling(False)
+        assert np.array_equal(n, n2), (k, n, n2)
+        for b in range(nb):
+            kk = int(n[b])
+            assert np.array_equal(dets[b]["anchor_index"][:kk], dets2[b]["anchor_index"][:kk])
+            assert np.array_equal(dets[b]["box3d_lidar"][:kk], dets2[b]["box3d_lidar"][:kk])
