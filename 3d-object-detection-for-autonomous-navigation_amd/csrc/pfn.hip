@@ -298,10 +298,13 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
         for (int s = 0; s < NS; ++s) sl += (g >= __builtin_amdgcn_readlane(incl, s)) ? 1 : 0;
         sl = min(sl, NS - 1);
         const int st = __shfl(start, sl), ex = __shfl(excl, sl);
+        const float pcx = __shfl(slot_cx, sl), pcy = __shfl(slot_cy, sl);
         if (g < tot) {
             r.slot = sl;
             const float* q = src + (size_t)sidx[st + (g - ex)] * F;
-            r.x = q[0]; r.y = q[1]; r.z = q[2];
+            r.x = q[0] - pcx;      // pillar-local coordinates (the reference's f_center features), one
+            r.y = q[1] - pcy;      // subtraction per point instead of one per point and lane
+            r.z = q[2];
             if (F > 3) r.i = q[F - 1];
         }
         return r;
@@ -361,26 +364,45 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
         cur_slot = s;
     };
     Batch cur = load_batch(0);
+    int left = 0;                                     // points of the current slot still to come (wave-uniform)
+    int next_slot = 0;
     for (int base = 0; base < tot; base += 64) {
         Batch nxt = cur;
         if (base + 64 < tot) nxt = load_batch(base + 64);
         const int nb = min(64, tot - base);
         for (int jj = 0; jj < nb; ++jj) {
-            const int s = __builtin_amdgcn_readlane(cur.slot, jj);
-            if (s != cur_slot) {
+            if (left == 0) {                          // slot boundary: the stream is slot-major, skip empty slots
                 if (cur_slot >= 0) finish_slot(cur_slot);
-                begin_slot(s);
+                while ((left = __builtin_amdgcn_readlane(cnt, next_slot)) == 0) ++next_slot;
+                begin_slot(next_slot);
+                ++next_slot;
             }
-            const float fx = bcast(cur.x, jj) - cxf, fy = bcast(cur.y, jj) - cyf, fz = bcast(cur.z, jj);
+            --left;
+            const float fx = bcast(cur.x, jj), fy = bcast(cur.y, jj), fz = bcast(cur.z, jj);
             const float fi = (F > 3) ? bcast(cur.i, jj) : 0.f;
             sx += fx; sy += fy; sz += fz;
+            if constexpr (CPL == 2) {                 // two channels per lane: packed fp32 math
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 vx = {fx, fx}, vy = {fy, fy}, vz = {fz, fz};
+                const f32x2 wx2 = {wsx[0], wsx[1]}, wy2 = {wsy[0], wsy[1]}, wz2 = {wsz[0], wsz[1]};
+                f32x2 o = vx * wx2;
+                o = __builtin_elementwise_fma(vy, wy2, o);
+                o = __builtin_elementwise_fma(vz, wz2, o);
+                if (F > 3) {
+                    const f32x2 vi = {fi, fi}, wi2 = {w[F - 1][0], w[F - 1][1]};
+                    o = __builtin_elementwise_fma(vi, wi2, o);
+                }
+                m[0] = fmaxf(m[0], o.x);
+                m[1] = fmaxf(m[1], o.y);
+            } else {
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                float o = fx * wsx[q];
-                o = fmaf(fy, wsy[q], o);
-                o = fmaf(fz, wsz[q], o);
-                if (F > 3) o = fmaf(fi, w[F - 1][q], o);
-                m[q] = fmaxf(m[q], o);
+                for (int q = 0; q < CPL; ++q) {
+                    float o = fx * wsx[q];
+                    o = fmaf(fy, wsy[q], o);
+                    o = fmaf(fz, wsz[q], o);
+                    if (F > 3) o = fmaf(fi, w[F - 1][q], o);
+                    m[q] = fmaxf(m[q], o);
+                }
             }
         }
         cur = nxt;
