@@ -306,6 +306,8 @@ def main():
         if "algorithmic_flops_per_launch" in roofline:
             extras["isolated_dominant"]["fp32_equivalent_tflops"] = roofline["algorithmic_flops_per_launch"] / t / 1e12
 
+    extras["kernel_time_over_wall"] = gpu_ms / ms_per_step   # > 1: kernels of the in-flight batches overlap
+
     # ---- per-step latency distribution of the same workload (synchronous steps) ----
     step_ms = []
     for _ in range(max(5, min(20, args.steps))):
