@@ -738,8 +738,12 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     const int n0 = blockIdx.y * NT;
     const int cin = a.cin;
     const int nchunks = cin / KCH;
-    const int dbg = a.dbg;
-    const int total = ntl * nchunks;                   // K-chunks in this workgroup's stream
+#ifdef PP_KERNEL_STAMPS
+    const int dbg = a.dbg;                             // phase ablation bits (diagnostic build only)
+#else
+    constexpr int dbg = 0;                             // production: no ablation branches inside the K loop
+#endif
+    const int total = ntl * nchunks;                   // K-chunks in this workgroup's stream (>= 2: cin >= 32)
 
     for (int e = tid; e < 9 * cin / 4; e += 256)
         reinterpret_cast<float4*>(sDW)[e] = reinterpret_cast<const float4*>(a.dw)[e];
@@ -822,123 +826,137 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     __syncthreads();   // depthwise taps visible
     U_STAMP(1)
 
-    for (int i = -1; i < total; ++i) {
-        if (i == 0) U_STAMP(2)
+    // ---- the parts of one stream position ----
+    // MFMAs of position I out of buffer I & 1
+#define U_MFMA(I)                                                                                        \
+    if (!(dbg & 1) && PREC == 1) {                                                                       \
+        const float* cA = sAw + ((I) & 1) * SAW + r32 * LSTR + h * (KCH / 2);                            \
+        const float* cB = sB + ((I) & 1) * SB + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);                  \
+        const float4 a0 = *reinterpret_cast<const float4*>(cA), a1 = *reinterpret_cast<const float4*>(cA + 4);  \
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};                            \
+        bf16x8 ah, am, al;                                                                               \
+        split_bf16x3(av, ah, am, al);                                                                    \
+        _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                             \
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);                         \
+            const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);                \
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);            \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);                   \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);                   \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);                   \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);                   \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);                   \
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);                   \
+        }                                                                                                \
+    }                                                                                                    \
+    if (!(dbg & 1) && PREC == 0) {                                                                       \
+        const float* cA = sAw + ((I) & 1) * SAW + r32 * LSTR + h * (KCH / 2);                            \
+        const float* cB = sB + ((I) & 1) * SB + r32 * LSTR + h * (KCH / 2);                              \
+        float4 a4[KQ];                                                                                   \
+        _Pragma("unroll") for (int qq = 0; qq < KQ; ++qq) a4[qq] = *reinterpret_cast<const float4*>(cA + qq * 4);  \
+        _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                             \
+            float4 b4[KQ];                                                                               \
+            _Pragma("unroll") for (int qq = 0; qq < KQ; ++qq) b4[qq] = *reinterpret_cast<const float4*>(cB + n * 32 * LSTR + qq * 4);  \
+            _Pragma("unroll") for (int qq = 0; qq < KQ; ++qq) {                                          \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].x, b4[qq].x, acc[n], 0, 0, 0);      \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].y, b4[qq].y, acc[n], 0, 0, 0);      \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].z, b4[qq].z, acc[n], 0, 0, 0);      \
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].w, b4[qq].w, acc[n], 0, 0, 0);      \
+            }                                                                                            \
+        }                                                                                                \
+    }
+    // stage position P (buffer P & 1): depthwise of this wave's pixels -> private A tile; weight share -> sB
+#define U_STAGE(P)                                                                                       \
+    {                                                                                                    \
+        const int buf = (P) & 1;                                                                         \
+        float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;                                            \
+        if (!(dbg & 2)) {                                                                                \
+            const float* tw = sDW + st_kc * KCH + c4 * 4;                                                \
+            _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                             \
+                _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                       \
+                    const float4 w4 = *reinterpret_cast<const float4*>(tw + (dy * 3 + dx) * cin);        \
+                    const float4 v0 = rin[dy * WW + dx], v1 = rin[dy * WW + S + dx];                     \
+                    o0.x = fmaf(v0.x, w4.x, o0.x); o0.y = fmaf(v0.y, w4.y, o0.y);                        \
+                    o0.z = fmaf(v0.z, w4.z, o0.z); o0.w = fmaf(v0.w, w4.w, o0.w);                        \
+                    o1.x = fmaf(v1.x, w4.x, o1.x); o1.y = fmaf(v1.y, w4.y, o1.y);                        \
+                    o1.z = fmaf(v1.z, w4.z, o1.z); o1.w = fmaf(v1.w, w4.w, o1.w);                        \
+                }                                                                                        \
+        }                                                                                                \
+        float* dA = sAw + buf * SAW + (2 * q) * LSTR + c4 * 4;                                           \
+        *reinterpret_cast<float4*>(dA) = o0;                                                             \
+        *reinterpret_cast<float4*>(dA + LSTR) = o1;                                                      \
+        if (NBI % 256 == 0 || NB4 > 1 || tid < NBI) *reinterpret_cast<float4*>(sB + buf * SB + bdst[0]) = rb0;  \
+        if (NB4 > 1 && (NBI >= 512 || tid + 256 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 1 ? 1 : 0]) = rb1;  \
+        if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 2 ? 2 : 0]) = rb2;  \
+        if (++st_kc == nchunks) st_kc = 0;                                                               \
+    }
+    // global loads of the next position of the load cursor
+#define U_ISSUE()                                                                                        \
+    {                                                                                                    \
+        if (ld_kc == 0) U_TILE_OFFSETS(ld_tile)                                                          \
+        U_LOAD_CHUNK(ld_kc)                                                                              \
+        if (++ld_kc == nchunks) { ld_kc = 0; ld_tile += GL; }                                            \
+    }
+    // tile finished: bias + ReLU, then a 4 x 4 register/lane transpose inside each lane quad turns "lane =
+    // channel, register = pixel row" into "lane holds 4 consecutive channels of one pixel": 16-byte stores, 8
+    // full 128-byte lines per instruction (few, large stores: the store path is bound by requests in flight,
+    // not bytes).  Issued AFTER the iteration's prefetch loads: the memory counter retires in issue order, so
+    // the next wait for those loads does not also wait for the stores' acknowledgements; the stores drain
+    // while the next tile's chunks are multiplied.
+#define U_EPILOGUE()                                                                                     \
+    {                                                                                                    \
+        const int pw = mm_tile * 128 + wave * 32;                                                        \
+        if (!(dbg & 4) && pw < a.M) {                                                                    \
+            const int qi = lane & 3, qj = r32 >> 2;                                                      \
+            float* dst = a.out + (size_t)(pw + 4 * h + qi) * a.ld_out + a.co_off + n0 + qj * 4;          \
+            const bool full = pw + 32 <= a.M;             /* wave-uniform */                             \
+            _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                         \
+                const float bvn = bias_r[n];                                                             \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                          \
+                    float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);  \
+                    float x2 = fmaxf(acc[n][4 * g + 2] + bvn, 0.f), x3 = fmaxf(acc[n][4 * g + 3] + bvn, 0.f);  \
+                    quad_transpose4(x0, x1, x2, x3, lane);                                               \
+                    if (full || pw + 8 * g + 4 * h + qi < a.M)                                           \
+                        *reinterpret_cast<float4*>(dst + (size_t)(8 * g) * a.ld_out + n * 32) = make_float4(x0, x1, x2, x3);  \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
+        _Pragma("unroll") for (int n = 0; n < NTILES; ++n)                                               \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;                              \
+        mm_kc = 0;                                                                                       \
+        mm_tile += GL;                                                                                   \
+    }
+
+    // prologue: stage position 0, issue the loads of position 1 (total >= 2)
+    U_STAGE(0)
+    U_ISSUE()
+    __syncthreads();
+    U_STAMP(2)
+    // steady state: positions i (MFMA), i+1 (staging) and i+2 (loads) all exist -- no branch between the
+    // MFMA block and the staging block, so the scheduler may interleave matrix and vector work
+    int i = 0;
+    for (; i + 2 < total; ++i) {
 #ifdef PP_KERNEL_STAMPS
         if (ust && blockIdx.x < 64 && i + 1 < 64) a.stamps[4096 * 8 + blockIdx.x * 64 + i + 1] = wall_clock64();
 #endif
-        bool tile_done = false;
-        if (i >= 0) {
-            // ---- MFMAs of position i out of buffer i & 1 ----
-            if (!(dbg & 1) && PREC == 1) {
-                const float* cA = sAw + (i & 1) * SAW + r32 * LSTR + h * (KCH / 2);
-                const float* cB = sB + (i & 1) * SB + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
-                const float4 a0 = *reinterpret_cast<const float4*>(cA), a1 = *reinterpret_cast<const float4*>(cA + 4);
-                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                bf16x8 ah, am, al;
-                split_bf16x3(av, ah, am, al);
-#pragma unroll
-                for (int n = 0; n < NTILES; ++n) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);
-                    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
-                }
-            }
-            if (!(dbg & 1) && PREC == 0) {
-                const float* cA = sAw + (i & 1) * SAW + r32 * LSTR + h * (KCH / 2);
-                const float* cB = sB + (i & 1) * SB + r32 * LSTR + h * (KCH / 2);
-                float4 a4[KQ];
-#pragma unroll
-                for (int qq = 0; qq < KQ; ++qq) a4[qq] = *reinterpret_cast<const float4*>(cA + qq * 4);
-#pragma unroll
-                for (int n = 0; n < NTILES; ++n) {
-                    float4 b4[KQ];
-#pragma unroll
-                    for (int qq = 0; qq < KQ; ++qq) b4[qq] = *reinterpret_cast<const float4*>(cB + n * 32 * LSTR + qq * 4);
-#pragma unroll
-                    for (int qq = 0; qq < KQ; ++qq) {
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].x, b4[qq].x, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].y, b4[qq].y, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].z, b4[qq].z, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qq].w, b4[qq].w, acc[n], 0, 0, 0);
-                    }
-                }
-            }
-            tile_done = (++mm_kc == nchunks);
-        }
-        if (i + 1 < total) {
-            // ---- stage position i+1: depthwise of this wave's pixels -> private A tile; weight share -> sB ----
-            const int buf = (i + 1) & 1;
-            float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
-            if (!(dbg & 2)) {
-                const float* tw = sDW + st_kc * KCH + c4 * 4;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const float4 w4 = *reinterpret_cast<const float4*>(tw + (dy * 3 + dx) * cin);
-                        const float4 v0 = rin[dy * WW + dx], v1 = rin[dy * WW + S + dx];
-                        o0.x = fmaf(v0.x, w4.x, o0.x); o0.y = fmaf(v0.y, w4.y, o0.y);
-                        o0.z = fmaf(v0.z, w4.z, o0.z); o0.w = fmaf(v0.w, w4.w, o0.w);
-                        o1.x = fmaf(v1.x, w4.x, o1.x); o1.y = fmaf(v1.y, w4.y, o1.y);
-                        o1.z = fmaf(v1.z, w4.z, o1.z); o1.w = fmaf(v1.w, w4.w, o1.w);
-                    }
-            }
-            float* dA = sAw + buf * SAW + (2 * q) * LSTR + c4 * 4;
-            *reinterpret_cast<float4*>(dA) = o0;
-            *reinterpret_cast<float4*>(dA + LSTR) = o1;
-            if (NBI % 256 == 0 || NB4 > 1 || tid < NBI) *reinterpret_cast<float4*>(sB + buf * SB + bdst[0]) = rb0;
-            if (NB4 > 1 && (NBI >= 512 || tid + 256 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 1 ? 1 : 0]) = rb1;
-            if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 2 ? 2 : 0]) = rb2;
-            if (++st_kc == nchunks) st_kc = 0;
-            if (i + 2 < total) {
-                if (ld_kc == 0) U_TILE_OFFSETS(ld_tile)
-                U_LOAD_CHUNK(ld_kc)
-                if (++ld_kc == nchunks) { ld_kc = 0; ld_tile += GL; }
-            }
-        }
-        if (tile_done) {
-            // ---- tile finished: bias + ReLU, then a 4 x 4 register/lane transpose inside each lane quad
-            // turns "lane = channel, register = pixel row" into "lane holds 4 consecutive channels of one
-            // pixel": 16-byte stores, 8 full 128-byte lines per instruction (few, large stores: the store
-            // path is bound by requests in flight, not bytes).  Issued AFTER this iteration's prefetch
-            // loads: the memory counter retires in issue order, so the next iteration's wait for those
-            // loads does not also wait for the stores' acknowledgements; the stores drain while the next
-            // tile's chunks are multiplied. ----
-            const int pw = mm_tile * 128 + wave * 32;
-            if (!(dbg & 4) && pw < a.M) {
-                const int qi = lane & 3, qj = r32 >> 2;
-                float* dst = a.out + (size_t)(pw + 4 * h + qi) * a.ld_out + a.co_off + n0 + qj * 4;
-                const bool full = pw + 32 <= a.M;             // wave-uniform
-#pragma unroll
-                for (int n = 0; n < NTILES; ++n) {
-                    const float bvn = bias_r[n];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);
-                        float x2 = fmaxf(acc[n][4 * g + 2] + bvn, 0.f), x3 = fmaxf(acc[n][4 * g + 3] + bvn, 0.f);
-                        quad_transpose4(x0, x1, x2, x3, lane);
-                        if (full || pw + 8 * g + 4 * h + qi < a.M)
-                            *reinterpret_cast<float4*>(dst + (size_t)(8 * g) * a.ld_out + n * 32) =
-                                make_float4(x0, x1, x2, x3);
-                    }
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < NTILES; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-            mm_kc = 0;
-            mm_tile += GL;
-        }
+        U_MFMA(i)
+        U_STAGE(i + 1)
+        U_ISSUE()
+        if (++mm_kc == nchunks) U_EPILOGUE()
         __syncthreads();
     }
+    // last two positions: nothing left to load, then nothing left to stage
+    U_MFMA(i)
+    U_STAGE(i + 1)
+    if (++mm_kc == nchunks) U_EPILOGUE()
+    __syncthreads();
+    ++i;
+    U_MFMA(i)
+    ++mm_kc;
+    U_EPILOGUE()
+#undef U_MFMA
+#undef U_STAGE
+#undef U_ISSUE
+#undef U_EPILOGUE
 #undef U_LOAD_CHUNK
 #undef U_TILE_OFFSETS
     U_STAMP(3)
@@ -1325,7 +1343,7 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
         const int unt = sep_u_nt(L, batch);
         const bool bf = L.d_wt16 != nullptr && split_precision(0);
         int wps;   // workgroups per CU of the instantiation launch_layer picks (launch_u<NT, S, WPS, WPB>)
-        if (L.stride == 1) wps = bf ? (unt == 128 ? 2 : (unt == 64 ? 3 : 4)) : (unt == 128 ? 3 : 4);
+        if (L.stride == 1) wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 3 : 4);
         else wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 2 : (unt == 64 ? 3 : 4));
         snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d,%d>", unt, L.stride, wps, bf ? 1 : 0);
     } else if (deconv_uniform(L, 0)) {
@@ -1366,7 +1384,7 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
             if (L.stride == 1) {
                 if (nt == 128) launch_u<128, 1, 3, 2>(a, L.n_total, s);
                 else if (nt == 64) launch_u<64, 1, 4, 3>(a, L.n_total, s);
-                else launch_u<32, 1, 4, 4>(a, L.n_total, s);
+                else launch_u<32, 1, 4, 3>(a, L.n_total, s);
             } else {
                 if (nt == 128) launch_u<128, 2, 2, 2>(a, L.n_total, s);
                 else if (nt == 64) launch_u<64, 2, 3, 3>(a, L.n_total, s);
