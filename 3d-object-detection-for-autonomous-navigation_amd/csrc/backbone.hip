@@ -796,15 +796,19 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     float4 rb0, rb1, rb2;
     rb0 = rb1 = rb2 = make_float4(0.f, 0.f, 0.f, 0.f);
     static_assert(NB4 <= 3, "weight prefetch registers");
-#define U_LOAD_CHUNK(KCIDX)                                                                              \
+#define U_LOAD_ACT(KCIDX, RIN)                                                                           \
     {                                                                                                    \
         const unsigned so_ = (unsigned)(KCIDX) * (KCH * 4);                                              \
+        _Pragma("unroll") for (int e = 0; e < NLD; ++e) RIN[e] = buf_load16(rs_in, aoff[e], so_);        \
+    }
+#define U_LOAD_WT(KCIDX)                                                                                 \
+    {                                                                                                    \
         const unsigned sb_ = (unsigned)(KCIDX) * bstep;                                                  \
-        _Pragma("unroll") for (int e = 0; e < NLD; ++e) rin[e] = buf_load16(rs_in, aoff[e], so_);        \
         if (NBI % 256 == 0 || NB4 > 1 || tid < NBI) rb0 = buf_load16(rs_wt, boff[0], sb_);               \
         if (NB4 > 1 && (NBI >= 512 || tid + 256 < NBI)) rb1 = buf_load16(rs_wt, boff[NB4 > 1 ? 1 : 0], sb_);  \
         if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) rb2 = buf_load16(rs_wt, boff[NB4 > 2 ? 2 : 0], sb_);  \
     }
+#define U_LOAD_CHUNK(KCIDX) { U_LOAD_ACT(KCIDX, rin) U_LOAD_WT(KCIDX) }
     // three cursors walk the stream of (tile, chunk) positions: loads are issued two positions ahead of
     // the MFMAs, staging runs one ahead
     int ld_tile = first, ld_kc = 0;      // next position whose loads get issued
@@ -865,7 +869,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         }                                                                                                \
     }
     // stage position P (buffer P & 1): depthwise of this wave's pixels -> private A tile; weight share -> sB
-#define U_STAGE(P)                                                                                       \
+#define U_STAGE2(P, RIN)                                                                                 \
     {                                                                                                    \
         const int buf = (P) & 1;                                                                         \
         float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;                                            \
@@ -874,7 +878,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
             _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                             \
                 _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                       \
                     const float4 w4 = *reinterpret_cast<const float4*>(tw + (dy * 3 + dx) * cin);        \
-                    const float4 v0 = rin[dy * WW + dx], v1 = rin[dy * WW + S + dx];                     \
+                    const float4 v0 = RIN[dy * WW + dx], v1 = RIN[dy * WW + S + dx];                     \
                     o0.x = fmaf(v0.x, w4.x, o0.x); o0.y = fmaf(v0.y, w4.y, o0.y);                        \
                     o0.z = fmaf(v0.z, w4.z, o0.z); o0.w = fmaf(v0.w, w4.w, o0.w);                        \
                     o1.x = fmaf(v1.x, w4.x, o1.x); o1.y = fmaf(v1.y, w4.y, o1.y);                        \
@@ -889,6 +893,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 2 ? 2 : 0]) = rb2;  \
         if (++st_kc == nchunks) st_kc = 0;                                                               \
     }
+#define U_STAGE(P) U_STAGE2(P, rin)
     // global loads of the next position of the load cursor
 #define U_ISSUE()                                                                                        \
     {                                                                                                    \
