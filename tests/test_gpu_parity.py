@@ -354,7 +354,8 @@ def test_error_behaviour(pp, engines):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"PP_GEMM_PREC": "f32"}, {"PP_GEMM_PREC": "f32", "PP_SEP_KERNEL": "ws"},
-                                 {"PP_PFN_KERNEL": "1"}])
+                                 {"PP_PFN_KERNEL": "1"}, {"PP_NO_HEAD_FUSION": "1"},
+                                 {"PP_NO_GRAPH": "1", "PP_SEP_NT": "64"}])
 def test_fallback_kernel_generations_stay_in_parity(hip_lib, env):
     """The earlier kernel generations are selectable at process start (fp32-MFMA instantiations, the
     producer/consumer GEMM, the first PFN); one child process per selection runs the whole path on two
