@@ -75,9 +75,12 @@ def make_annos(nframes):
             names[-1] = "Cyclist" if f % 2 else "Person_sitting"
         occ = rng.integers(0, 3, ng_)
         trunc = rng.choice([0.0, 0.1, 0.25, 0.4], ng_)
+        bbox_gt = np.stack([100.0 + 40 * np.arange(ng_), np.full(ng_, 100.0), 180.0 + 40 * np.arange(ng_),
+                            200.0 + 20 * (f % 3) + rng.uniform(-70, 10, ng_)], 1) if ng_ else np.zeros((0, 4))
+        if ng_ >= 2 and f % 3 == 0:
+            names[0] = "DontCare"               # exercises the dc_bboxes branch of the 2D metric
         gt = {"name": names, "truncated": trunc, "occluded": occ, "alpha": -np.arctan2(-loc[:, 0], loc[:, 2]) + rot,
-              "bbox": np.tile(np.array([[100.0, 100.0, 200.0, 200.0 + 20 * (f % 3)]]), (ng_, 1)),
-              "dimensions": dims, "location": loc, "rotation_y": rot}
+              "bbox": bbox_gt, "dimensions": dims, "location": loc, "rotation_y": rot}
         # detections: jittered copies of most gts + false positives
         keep = rng.uniform(size=ng_) < 0.8
         nd_fp = int(rng.integers(0, 3))
@@ -90,7 +93,10 @@ def make_annos(nframes):
         nd = dloc.shape[0]
         dt = {"name": np.array(["Pedestrian"] * nd), "truncated": np.zeros(nd), "occluded": np.zeros(nd, dtype=np.int64),
               "alpha": -np.arctan2(-dloc[:, 0], dloc[:, 2]) + drot if nd else np.zeros(0),
-              "bbox": np.tile(np.array([[400.0, 200.0, 500.0, 400.0]]), (nd, 1)), "dimensions": ddims, "location": dloc,
+              "bbox": (np.concatenate([bbox_gt[keep] + rng.normal(0, 4, (int(keep.sum()), 4)),
+                                       np.tile(np.array([[400.0, 200.0, 500.0, 215.0 + 60 * (f % 2)]]), (nd_fp, 1))], 0)
+                       if nd else np.zeros((0, 4))),
+              "dimensions": ddims, "location": dloc,
               "rotation_y": drot, "score": rng.uniform(0.05, 0.99, nd).astype(np.float32)}
         gts.append(gt)
         dts.append(dt)
