@@ -667,16 +667,24 @@ __device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2,
 // as the six products whose weight is >= 2^-16 relative (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid)
 // on the bf16 matrix pipe with float32 accumulation: float32-equivalent accuracy (the dropped terms
 // are < 2^-24 relative) at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 16 channels.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    // two values at a time: one v_cvt_pk_bf16_f32 per pair and piece; the bf16 -> f32 widening is a shift / a mask
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)v[j];
-        const float r1 = v[j] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        hi[j] = h;
-        mid[j] = m;
-        lo[j] = (__bf16)r2;
+    for (int j = 0; j < 8; j += 2) {
+        const f32x2_t x = {v[j], v[j + 1]};
+        const bf16x2_t h = __builtin_convertvector(x, bf16x2_t);
+        const unsigned hu = __builtin_bit_cast(unsigned, h);
+        // (scalar subtractions on purpose: packed fp32 adds are slow beside MFMAs)
+        const f32x2_t r1 = {v[j] - __uint_as_float(hu << 16), v[j + 1] - __uint_as_float(hu & 0xffff0000u)};
+        const bf16x2_t m = __builtin_convertvector(r1, bf16x2_t);
+        const unsigned mu = __builtin_bit_cast(unsigned, m);
+        const f32x2_t r2 = {r1.x - __uint_as_float(mu << 16), r1.y - __uint_as_float(mu & 0xffff0000u)};
+        const bf16x2_t l = __builtin_convertvector(r2, bf16x2_t);
+        hi[j] = h.x; hi[j + 1] = h.y;
+        mid[j] = m.x; mid[j + 1] = m.y;
+        lo[j] = l.x; lo[j + 1] = l.y;
     }
 }
 
@@ -745,8 +753,15 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
 #endif
     const int total = ntl * nchunks;                   // K-chunks in this workgroup's stream (>= 2: cin >= 32)
 
-    for (int e = tid; e < 9 * cin / 4; e += 256)
-        reinterpret_cast<float4*>(sDW)[e] = reinterpret_cast<const float4*>(a.dw)[e];
+    // depthwise taps -> LDS as [channel group of 4][9 taps][4 channels]: the 9 tap vectors of a lane's channel
+    // group are 16 bytes apart (immediate offsets on one base address, which moves 576 bytes per K-chunk)
+    {
+        const int ngrp = cin / 4;
+        for (int e = tid; e < 9 * ngrp; e += 256) {
+            const int t = e / ngrp, g4 = e - t * ngrp;
+            reinterpret_cast<float4*>(sDW)[g4 * 9 + t] = reinterpret_cast<const float4*>(a.dw)[e];
+        }
+    }
 
     // ---- staging role: lane (q, c4) owns output pixels pw + 2q, +1 and channels 4*c4..+3 of a chunk ----
     const int c4 = lane & 3, q = lane >> 2;
@@ -834,8 +849,8 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     // MFMAs of position I out of buffer I & 1
 #define U_MFMA(I)                                                                                        \
     if (!(dbg & 1) && PREC == 1) {                                                                       \
-        const float* cA = sAw + ((I) & 1) * SAW + r32 * LSTR + h * (KCH / 2);                            \
-        const float* cB = sB + ((I) & 1) * SB + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);                  \
+        const float* cA = cA0 + ((I) & 1) * SAW;                                                         \
+        const float* cB = cB0 + ((I) & 1) * SB;                                                          \
         const float4 a0 = *reinterpret_cast<const float4*>(cA), a1 = *reinterpret_cast<const float4*>(cA + 4);  \
         const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};                            \
         bf16x8 ah, am, al;                                                                               \
@@ -871,13 +886,13 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     // stage position P (buffer P & 1): depthwise of this wave's pixels -> private A tile; weight share -> sB
 #define U_STAGE2(P, RIN)                                                                                 \
     {                                                                                                    \
-        const int buf = (P) & 1;                                                                         \
+        constexpr int buf = (P) & 1;   /* the steady loop is unrolled by two: buffer parities are static */ \
         float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;                                            \
         if (!(dbg & 2)) {                                                                                \
-            const float* tw = sDW + st_kc * KCH + c4 * 4;                                                \
+            const float* tw = twp;                                                                       \
             _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                             \
                 _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                       \
-                    const float4 w4 = *reinterpret_cast<const float4*>(tw + (dy * 3 + dx) * cin);        \
+                    const float4 w4 = *reinterpret_cast<const float4*>(tw + (dy * 3 + dx) * 4);          \
                     const float4 v0 = RIN[dy * WW + dx], v1 = RIN[dy * WW + S + dx];                     \
                     o0.x = fmaf(v0.x, w4.x, o0.x); o0.y = fmaf(v0.y, w4.y, o0.y);                        \
                     o0.z = fmaf(v0.z, w4.z, o0.z); o0.w = fmaf(v0.w, w4.w, o0.w);                        \
@@ -891,7 +906,8 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         if (NBI % 256 == 0 || NB4 > 1 || tid < NBI) *reinterpret_cast<float4*>(sB + buf * SB + bdst[0]) = rb0;  \
         if (NB4 > 1 && (NBI >= 512 || tid + 256 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 1 ? 1 : 0]) = rb1;  \
         if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 2 ? 2 : 0]) = rb2;  \
-        if (++st_kc == nchunks) st_kc = 0;                                                               \
+        twp += 4 * 36;                                                                                   \
+        if (++st_kc == nchunks) { st_kc = 0; twp = sDW + c4 * 36; }                                      \
     }
 #define U_STAGE(P) U_STAGE2(P, rin)
     // global loads of the next position of the load cursor
@@ -931,6 +947,9 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         mm_tile += GL;                                                                                   \
     }
 
+    const float* twp = sDW + c4 * 36;                  // this lane's tap vectors of the next chunk to stage
+    const float* const cA0 = sAw + r32 * LSTR + h * (KCH / 2);                       // fragment read bases (PREC 1)
+    const float* const cB0 = sB + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
     // prologue: stage position 0, issue the loads of position 1 (total >= 2)
     U_STAGE(0)
     U_ISSUE()
@@ -938,24 +957,29 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     U_STAMP(2)
     // steady state: positions i (MFMA), i+1 (staging) and i+2 (loads) all exist -- no branch between the
     // MFMA block and the staging block, so the scheduler may interleave matrix and vector work
+    // (unrolled by two -- total is even -- so that the LDS buffer of every access is a compile-time constant)
     int i = 0;
-    for (; i + 2 < total; ++i) {
+    for (; i + 3 < total; i += 2) {
 #ifdef PP_KERNEL_STAMPS
         if (ust && blockIdx.x < 64 && i + 1 < 64) a.stamps[4096 * 8 + blockIdx.x * 64 + i + 1] = wall_clock64();
 #endif
-        U_MFMA(i)
-        U_STAGE(i + 1)
+        U_MFMA(0)
+        U_STAGE(1)
+        U_ISSUE()
+        if (++mm_kc == nchunks) U_EPILOGUE()
+        __syncthreads();
+        U_MFMA(1)
+        U_STAGE(0)
         U_ISSUE()
         if (++mm_kc == nchunks) U_EPILOGUE()
         __syncthreads();
     }
-    // last two positions: nothing left to load, then nothing left to stage
-    U_MFMA(i)
-    U_STAGE(i + 1)
+    // last two positions (i even): nothing left to load, then nothing left to stage
+    U_MFMA(0)
+    U_STAGE(1)
     if (++mm_kc == nchunks) U_EPILOGUE()
     __syncthreads();
-    ++i;
-    U_MFMA(i)
+    U_MFMA(1)
     ++mm_kc;
     U_EPILOGUE()
 #undef U_MFMA
