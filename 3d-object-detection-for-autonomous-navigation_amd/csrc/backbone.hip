@@ -688,6 +688,15 @@ __device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8& hi, bf
     }
 }
 
+// n / d and n % d for 0 <= n < 2^24 (exact in float32) with a precomputed reciprocal: a multiply, a
+// truncation and one correction step each way instead of the ~40-instruction integer division
+__device__ __forceinline__ void fast_divmod(int n, int d, float inv_d, int& q, int& r) {
+    q = (int)((float)n * inv_d);
+    r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+}
+
 // ---------------------------------------------------------------------------------------
 // Uniform-wave separable layer (every wave prepares AND multiplies).
 //
@@ -768,6 +777,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(PREC == 0 ? (const void*)a.wt : (const void*)a.wt16);
     const int hw = a.px_h * a.px_w;
+    const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)a.px_w;
     const int rs4 = a.in_w * cin * 4, cin4 = cin * 4;
     unsigned aoff[NLD];
     // byte offsets of the 3 x WW window of this lane's pixel pair in tile `tile` (out-of-map -> zero header)
@@ -776,9 +786,9 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         const int pix0_ = (TILE) * 128 + wave * 32 + 2 * q;                                              \
         const bool pvalid_ = pix0_ < a.M;                                                                \
         const int pc_ = pvalid_ ? pix0_ : 0;                                                             \
-        const int b_ = pc_ / hw;                                                                         \
-        const int rem_ = pc_ - b_ * hw;                                                                  \
-        const int y_ = rem_ / a.px_w, x0_ = rem_ - y_ * a.px_w;                                          \
+        int b_, rem_, y_, x0_;                                                                           \
+        fast_divmod(pc_, hw, inv_hw, b_, rem_);        /* pixel counts < 2^24 (checked by the launcher) */ \
+        fast_divmod(rem_, a.px_w, inv_w, y_, x0_);                                                       \
         const int yi_ = y_ * S - 1, xi_ = x0_ * S - 1;                                                   \
         const unsigned cbase_ =                                                                          \
             (unsigned)(((b_ * a.in_h + y_ * S) * a.in_w + x0_ * S) * cin) * 4u + PP_ZPAD_FLOATS * 4u;    \
@@ -929,15 +939,28 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         if (!(dbg & 4) && pw < a.M) {                                                                    \
             const int qi = lane & 3, qj = r32 >> 2;                                                      \
             float* dst = a.out + (size_t)(pw + 4 * h + qi) * a.ld_out + a.co_off + n0 + qj * 4;          \
-            const bool full = pw + 32 <= a.M;             /* wave-uniform */                             \
-            _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                         \
-                const float bvn = bias_r[n];                                                             \
-                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                          \
-                    float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);  \
-                    float x2 = fmaxf(acc[n][4 * g + 2] + bvn, 0.f), x3 = fmaxf(acc[n][4 * g + 3] + bvn, 0.f);  \
-                    quad_transpose4(x0, x1, x2, x3, lane);                                               \
-                    if (full || pw + 8 * g + 4 * h + qi < a.M)                                           \
-                        *reinterpret_cast<float4*>(dst + (size_t)(8 * g) * a.ld_out + n * 32) = make_float4(x0, x1, x2, x3);  \
+            const bool full = pw + 32 <= a.M;             /* wave-uniform: one branch, not one per store */ \
+            const int ldo = a.ld_out;                                                                    \
+            if (full) {                                                                                  \
+                _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                     \
+                    const float bvn = bias_r[n];                                                         \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                      \
+                        float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);  \
+                        float x2 = fmaxf(acc[n][4 * g + 2] + bvn, 0.f), x3 = fmaxf(acc[n][4 * g + 3] + bvn, 0.f);  \
+                        quad_transpose4(x0, x1, x2, x3, lane);                                           \
+                        *reinterpret_cast<float4*>(dst + (8 * g) * ldo + n * 32) = make_float4(x0, x1, x2, x3);  \
+                    }                                                                                    \
+                }                                                                                        \
+            } else {                                                                                     \
+                _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                     \
+                    const float bvn = bias_r[n];                                                         \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                      \
+                        float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);  \
+                        float x2 = fmaxf(acc[n][4 * g + 2] + bvn, 0.f), x3 = fmaxf(acc[n][4 * g + 3] + bvn, 0.f);  \
+                        quad_transpose4(x0, x1, x2, x3, lane);                                           \
+                        if (pw + 8 * g + 4 * h + qi < a.M)                                               \
+                            *reinterpret_cast<float4*>(dst + (8 * g) * ldo + n * 32) = make_float4(x0, x1, x2, x3);  \
+                    }                                                                                    \
                 }                                                                                        \
             }                                                                                            \
         }                                                                                                \
@@ -1368,7 +1391,7 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
     const int nt = (L.kind == LAYER_HEAD) ? 32 : (L.cout % 128 == 0 ? 128 : (L.cout % 64 == 0 ? 64 : 32));
     const int mode = (L.kind == LAYER_SEP) ? 0 : 1;
     char buf[64];
-    if (L.kind == LAYER_SEP && use_ws(L) && sep_uniform(0)) {
+    if (L.kind == LAYER_SEP && use_ws(L) && sep_uniform(0) && layer_rows(L, batch) < (1 << 24)) {
         const int unt = sep_u_nt(L, batch);
         const bool bf = L.d_wt16 != nullptr && split_precision(0);
         int wps;   // workgroups per CU of the instantiation launch_layer picks (launch_u<NT, S, WPS, WPB>)
@@ -1408,7 +1431,7 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
         a.px_h = L.out_h; a.px_w = L.out_w; a.epi = 0;
         a.M = batch * L.out_h * L.out_w;
         if (L.cout % 32 != 0) return PP_ERR_UNSUPPORTED;
-        if (use_ws(L) && sep_uniform(ablate)) {
+        if (use_ws(L) && sep_uniform(ablate) && a.M < (1 << 24)) {   // k_sep_u's float-reciprocal index math
             const int nt = sep_u_nt(L, batch);
             if (L.stride == 1) {
                 if (nt == 128) launch_u<128, 1, 3, 2>(a, L.n_total, s);
