@@ -286,17 +286,47 @@ def main():
     # ---- the same kernels with ONE batch in flight (no overlap between streams): isolated durations and the
     # dominant kernel's roof fractions without the co-running kernel's share of the chip ----
     eng.set_profiling(True)
-    iso = {}
+    iso, iso_layer = {}, {}
     for _ in range(4):
         eng.detect_async()
         eng.sync()
         for tag, ms in eng.kernel_times():
-            sym = tag.partition(":")[0]
+            sym, _, layer = tag.partition(":")
             a = iso.setdefault(sym, [0.0, 0])
             a[0] += ms
             a[1] += 1
+            if layer:
+                al = iso_layer.setdefault(layer, [0.0, 0, sym])
+                al[0] += ms
+                al[1] += 1
     eng.set_profiling(False)
     extras["isolated_avg_launch_ms"] = {k: round(v[0] / v[1], 4) for k, v in sorted(iso.items(), key=lambda kv: -kv[1][0])}
+    # every stage against its roofs, isolated (one batch in flight): algorithmic bytes / flops per launch over the
+    # HIP-event duration; GEMM layers get both roofs, the other kernels the HBM roof
+    lbytes = layer_bytes(d, B, heads_fused)
+    roofs = {}
+    for layer, (tms, cnt, sym) in iso_layer.items():
+        t = tms / cnt * 1e-3
+        if layer in lf:
+            split = sym.startswith("k_deconv_u") or (sym.startswith("k_sep_u") and sym.endswith(",1>"))
+            peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_TERMS if split else F32_MFMA_PEAK_TFLOPS
+            roofs[layer] = {"kernel": sym, "ms": round(t * 1e3, 4), "GBps": round(lbytes[layer] / t / 1e9, 1),
+                            "frac_hbm": round(lbytes[layer] / t / 1e9 / HBM_PEAK_GBS, 3),
+                            "fp32_equiv_TFLOPs": round(lf[layer] / t / 1e12, 1),
+                            "frac_mfma": round(lf[layer] / t / 1e12 / peak, 3)}
+        else:
+            key = sym.split("(")[0]
+            nbytes = sb.get(key)
+            if nbytes:
+                roofs[layer] = {"kernel": sym, "ms": round(t * 1e3, 4), "GBps": round(nbytes / t / 1e9, 1),
+                                "frac_hbm": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 3)}
+    for sym, (tms, cnt) in iso.items():
+        key = sym.split("(")[0]
+        if key in sb and not any(v["kernel"] == sym for v in roofs.values()):
+            t = tms / cnt * 1e-3
+            roofs[key] = {"kernel": sym, "ms": round(t * 1e3, 4), "GBps": round(sb[key] / t / 1e9, 1),
+                          "frac_hbm": round(sb[key] / t / 1e9 / HBM_PEAK_GBS, 3)}
+    extras["isolated_roofs"] = roofs
     if dominant in iso and "algorithmic_bytes_per_launch" in roofline:
         t = iso[dominant][0] / iso[dominant][1] * 1e-3
         extras["isolated_dominant"] = {
