@@ -148,6 +148,11 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # communicator set-up (and RCCL's device buffers) now, before any engine memory or graph exists
+        warm = torch.ones(1, device=f"cuda:{local_rank}")
+        dist.all_reduce(warm)
+        dist.barrier()
+        torch.cuda.synchronize()
     n_gpus = world if world > 1 else 1
 
     import pp_amd as pp
