@@ -1036,6 +1036,191 @@ static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
         hipLaunchKernelGGL((k_sep_u<NT, S, WPS, 0>), grid, dim3(256), 0, s, a, ntiles);
 }
 
+// ---------------------------------------------------------------------------------------
+// Split-K separable layer for small maps (few frames in flight: the latency case).
+//
+// With a handful of 32-pixel wave tiles the chip is empty and a layer's time is the length of ONE
+// wave's dependent chain: cin / 16 K-chunks of load -> depthwise -> LDS -> MFMA.  Here the four waves
+// of a workgroup share one 32-pixel x NT tile and split the K range instead: wave w takes chunks w,
+// w + 4, ...; each wave has its own A and weight tiles in LDS (no workgroup barrier inside the K loop),
+// and the four partial accumulators are added through LDS in a fixed order (deterministic), wave n
+// finishing channel tile n (bias, ReLU, 16-byte stores).  The chain is a quarter as long.
+// Split-precision bf16 only; cin % 64 == 0.
+template <int NT, int S>
+__global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
+    constexpr int KCH = 16, LSTR = KCH + 4;
+    constexpr int WW = S + 3, NLD = 3 * WW;
+    constexpr int SAW = 32 * LSTR;              // one A buffer (floats)
+    constexpr int SB = 3 * NT * 8;              // one weight buffer: [3 pieces][NT][16 bf16]
+    constexpr int NTILES = NT / 32;
+    constexpr int NBL = NT * 6 / 64;            // 16-byte weight items per lane per chunk
+    constexpr int WV = 2 * SAW + 2 * SB;        // floats per wave
+    static_assert(4 * NTILES * 16 * 64 <= 4 * WV, "reduction scratch overlays the staging tiles");
+    __shared__ __attribute__((aligned(16))) float smem[4 * WV + 9 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* const sAw = smem + wave * WV;
+    float* const sBw = sAw + 2 * SAW;
+    float* const sDW = smem + 4 * WV;
+    const int n0 = blockIdx.y * NT;
+    const int cin = a.cin;
+    const int niter = cin / (KCH * 4);          // chunks per wave (>= 1, checked by the launcher)
+
+    {
+        const int ngrp = cin / 4;
+        for (int e = tid; e < 9 * ngrp; e += 256) {
+            const int t = e / ngrp, g4 = e - t * ngrp;
+            reinterpret_cast<float4*>(sDW)[g4 * 9 + t] = reinterpret_cast<const float4*>(a.dw)[e];
+        }
+    }
+    const int c4 = lane & 3, q = lane >> 2;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc((const void*)a.wt16);
+    unsigned aoff[NLD];
+    {
+        const int hw = a.px_h * a.px_w;
+        const int pix0 = blockIdx.x * 32 + 2 * q;
+        const bool pvalid = pix0 < a.M;
+        const int pc = pvalid ? pix0 : 0;
+        const int b = pc / hw, rem = pc - b * hw;
+        const int y = rem / a.px_w, x0 = rem - y * a.px_w;
+        const int yi = y * S - 1, xi = x0 * S - 1;
+        const int rs4 = a.in_w * cin * 4, cin4 = cin * 4;
+        const unsigned cbase = (unsigned)(((b * a.in_h + y * S) * a.in_w + x0 * S) * cin) * 4u + PP_ZPAD_FLOATS * 4u;
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            const int dy = e / WW, dx = e % WW;
+            const bool ok = pvalid && yi + dy >= 0 && yi + dy < a.in_h && xi + dx >= 0 && xi + dx < a.in_w;
+            aoff[e] = (ok ? cbase + (unsigned)((dy - 1) * rs4 + (dx - 1) * cin4) : 0u) + (unsigned)(c4 * 16);
+        }
+    }
+    unsigned boff[NBL];
+    int bdst[NBL];
+#pragma unroll
+    for (int r = 0; r < NBL; ++r) {
+        const int e = lane + 64 * r;
+        const int piece = e / (NT * 2), rem = e % (NT * 2), row = rem >> 1, half = rem & 1;
+        boff[r] = (unsigned)(((piece * a.n_total + n0 + row) * 16 + half * 8) * 2);
+        bdst[r] = piece * (NT * 8) + row * 8 + ((half ^ ((row >> 3) & 1)) * 4);
+    }
+    const unsigned bstep = (unsigned)(3 * a.n_total * 32);   // bytes per K-chunk of the split weights
+    float4 rin[NLD];
+    float4 rb[NBL];
+#define K4_LOAD(KC)                                                                                      \
+    {                                                                                                    \
+        const unsigned so_ = (unsigned)(KC) * (KCH * 4), sb_ = (unsigned)(KC) * bstep;                   \
+        _Pragma("unroll") for (int e = 0; e < NLD; ++e) rin[e] = buf_load16(rs_in, aoff[e], so_);        \
+        _Pragma("unroll") for (int r = 0; r < NBL; ++r) rb[r] = buf_load16(rs_wt, boff[r], sb_);         \
+    }
+#define K4_STAGE(KC, BUF)                                                                                \
+    {                                                                                                    \
+        const float* tw = sDW + ((KC) * 4 + c4) * 36;                                                    \
+        float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;                                            \
+        _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                 \
+            _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                           \
+                const float4 w4 = *reinterpret_cast<const float4*>(tw + (dy * 3 + dx) * 4);              \
+                const float4 v0 = rin[dy * WW + dx], v1 = rin[dy * WW + S + dx];                         \
+                o0.x = fmaf(v0.x, w4.x, o0.x); o0.y = fmaf(v0.y, w4.y, o0.y);                            \
+                o0.z = fmaf(v0.z, w4.z, o0.z); o0.w = fmaf(v0.w, w4.w, o0.w);                            \
+                o1.x = fmaf(v1.x, w4.x, o1.x); o1.y = fmaf(v1.y, w4.y, o1.y);                            \
+                o1.z = fmaf(v1.z, w4.z, o1.z); o1.w = fmaf(v1.w, w4.w, o1.w);                            \
+            }                                                                                            \
+        float* dA = sAw + (BUF) * SAW + (2 * q) * LSTR + c4 * 4;                                         \
+        *reinterpret_cast<float4*>(dA) = o0;                                                             \
+        *reinterpret_cast<float4*>(dA + LSTR) = o1;                                                      \
+        _Pragma("unroll") for (int r = 0; r < NBL; ++r)                                                  \
+            *reinterpret_cast<float4*>(sBw + (BUF) * SB + bdst[r]) = rb[r];                              \
+    }
+    K4_LOAD(wave)
+    f32x16 acc[NTILES];
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const int h = lane >> 5, r32 = lane & 31;
+    const float bias_w = (wave < NTILES) ? a.bias[n0 + wave * 32 + r32] : 0.f;
+    __syncthreads();   // depthwise taps visible
+    K4_STAGE(wave, 0)
+    if (niter > 1) K4_LOAD(wave + 4)
+    const float* const cA0 = sAw + r32 * LSTR + h * (KCH / 2);
+    const float* const cB0 = sBw + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+#pragma unroll 1
+    for (int j = 0; j < niter; ++j) {
+        const int buf = j & 1;
+        {
+            const float* cA = cA0 + buf * SAW;
+            const float* cB = cB0 + buf * SB;
+            const float4 a0 = *reinterpret_cast<const float4*>(cA), a1 = *reinterpret_cast<const float4*>(cA + 4);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            bf16x8 ah, am, al;
+            split_bf16x3(av, ah, am, al);
+#pragma unroll
+            for (int n = 0; n < NTILES; ++n) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+            }
+        }
+        if (j + 1 < niter) {
+            K4_STAGE(wave + 4 * (j + 1), buf ^ 1)
+            if (j + 2 < niter) K4_LOAD(wave + 4 * (j + 2))
+        }
+    }
+#undef K4_LOAD
+#undef K4_STAGE
+    // ---- add the four partial sums: [wave][channel tile][register group][lane][4] through LDS ----
+    __syncthreads();   // every wave is done with its staging tiles
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(smem + (((wave * NTILES + n) * 4 + g) * 64 + lane) * 4) =
+                make_float4(acc[n][4 * g], acc[n][4 * g + 1], acc[n][4 * g + 2], acc[n][4 * g + 3]);
+    __syncthreads();
+    const int pw = blockIdx.x * 32;
+    if (wave < NTILES) {
+        const int qi = lane & 3, qj = r32 >> 2;
+        float* dst = a.out + (size_t)(pw + 4 * h + qi) * a.ld_out + a.co_off + n0 + wave * 32 + qj * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 t = *reinterpret_cast<const float4*>(smem + (((0 * NTILES + wave) * 4 + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 u = *reinterpret_cast<const float4*>(smem + (((w * NTILES + wave) * 4 + g) * 64 + lane) * 4);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            float x0 = fmaxf(t.x + bias_w, 0.f), x1 = fmaxf(t.y + bias_w, 0.f);
+            float x2 = fmaxf(t.z + bias_w, 0.f), x3 = fmaxf(t.w + bias_w, 0.f);
+            quad_transpose4(x0, x1, x2, x3, lane);
+            if (pw + 8 * g + 4 * h + qi < a.M)
+                *reinterpret_cast<float4*>(dst + (size_t)(8 * g) * a.ld_out) = make_float4(x0, x1, x2, x3);
+        }
+    }
+}
+
+// the split-K kernel runs a layer while the map is too small to fill the chip with 32-pixel wave tiles.
+// Measured crossover against k_sep_u (tools/k4_sweep.sh, cfg-A, B = 2..16): 1.5 workgroups per CU for
+// cin = 64, 2.5 for cin = 128, 3 for cin = 256 -- the longer the K chain, the later k_sep_u catches up.
+// PP_SEP_K4=0 turns it off, PP_SEP_K4=n sets the limit to n workgroups per CU for every layer.
+static bool sep_k4_runs(const void* wt16, int cin, int n_total, long long M, int dbg) {
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("PP_SEP_K4"); force = e ? atoi(e) : -1; }
+    if (force == 0 || wt16 == nullptr || !split_precision(dbg) || cin % 64 != 0 || cin > 256 || n_total % 64 != 0)
+        return false;
+    const int half_cus = (force > 0) ? 2 * force : (cin <= 64 ? 3 : (cin <= 128 ? 5 : 6));
+    return 2 * ((M + 31) / 32 * (n_total / 64)) <= (long long)half_cus * g_num_cus;
+}
+template <int S>
+static void launch_k4(const GemmArgs& a, int n_total, hipStream_t s) {
+    dim3 grid((unsigned)((a.M + 31) / 32), n_total / 64);
+    hipLaunchKernelGGL((k_sep_k4<64, S>), grid, dim3(256), 0, s, a);
+}
+
 // Epilogue of one 128-pixel deconv tile (see k_deconv_u).  Accumulator layout (operands swapped in the
 // MFMAs): lane & 31 = pixel of the wave's 32, register r of tile n = channel n*32 + DCH(r, h).
 #define DCH(R, H) (((R) & 3) + 8 * ((R) >> 2) + 4 * (H))
@@ -1392,6 +1577,10 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
     const int mode = (L.kind == LAYER_SEP) ? 0 : 1;
     char buf[64];
     if (L.kind == LAYER_SEP && use_ws(L) && sep_uniform(0) && layer_rows(L, batch) < (1 << 24)) {
+        if (sep_k4_runs(L.d_wt16, L.cin, L.n_total, layer_rows(L, batch), 0)) {
+            snprintf(buf, sizeof(buf), "k_sep_k4<64,%d>", L.stride);
+            return std::string(buf);
+        }
         const int unt = sep_u_nt(L, batch);
         const bool bf = L.d_wt16 != nullptr && split_precision(0);
         int wps;   // workgroups per CU of the instantiation launch_layer picks (launch_u<NT, S, WPS, WPB>)
@@ -1433,7 +1622,10 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
         if (L.cout % 32 != 0) return PP_ERR_UNSUPPORTED;
         if (use_ws(L) && sep_uniform(ablate) && a.M < (1 << 24)) {   // k_sep_u's float-reciprocal index math
             const int nt = sep_u_nt(L, batch);
-            if (L.stride == 1) {
+            if (!(ablate & 16) && sep_k4_runs(a.wt16, a.cin, L.n_total, a.M, ablate)) {   // small map
+                if (L.stride == 1) launch_k4<1>(a, L.n_total, s);
+                else launch_k4<2>(a, L.n_total, s);
+            } else if (L.stride == 1) {
                 if (nt == 128) launch_u<128, 1, 3, 2>(a, L.n_total, s);
                 else if (nt == 64) launch_u<64, 1, 4, 3>(a, L.n_total, s);
                 else launch_u<32, 1, 4, 3>(a, L.n_total, s);

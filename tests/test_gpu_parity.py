@@ -138,6 +138,34 @@ def test_forward_matches_oracle(pp, engines, name, nframes, npts):
         assert len(np.unique(yx)) < len(yx)
 
 
+def test_small_map_split_k_kernel_ragged_tiles(pp, engines):
+    """Few frames on a small map run the split-K separable kernel (k_sep_k4); a 28x20 grid makes the
+    pixel counts of block1 / block2 (560 / 140 per frame) end inside a 32-pixel tile, and block3's odd
+    width (7) takes the generic kernel.  Full-width layers (64/128/256 channels), against the oracle."""
+    import copy
+    B = 2
+    cfg = copy.deepcopy(pp.config.pedestrian_d435i_config(B))
+    cfg["eval_input_reader"]["feature_map_size"] = [1, 20, 28]
+    s = cfg["model"]["second"]
+    s["voxel_generator"].update(point_cloud_range=[0, -0.8, -3.0, 2.24, 0.8, 3.0], max_number_of_voxels=560)
+    s["target_assigner"]["anchor_generators"]["anchor_generator_stride"].update(offsets=[0.08, -0.8, -1.465])
+    eng = engines("net-ragged", cfg, max_batch=B, weights_seed=11)
+    d = eng.d
+    assert (d.nx, d.ny) == (28, 20)
+    tags = eng.layer_tags()
+    assert any(t.startswith("k_sep_k4") for t in tags), tags
+    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=11))
+    rng = np.random.default_rng(21)
+    frames = [rng.uniform([0, -0.8, -3], [2.24, 0.8, 3], (n, 3)).astype(np.float32) for n in (3000, 1700)]
+    rect, trv, p2 = pp.synth.default_calib()
+    ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
+    ex = ref["example"]
+    out = eng.forward_voxels(ex[0], ex[1], ex[2], B)
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        assert out[k].shape == ref["preds"][k].shape
+        np.testing.assert_allclose(out[k], ref["preds"][k], rtol=TOL, atol=TOL)
+
+
 # ------------------------------------------------------------------ a8-a12
 def _assert_dets(pp_dicts, ref_dicts):
     assert len(pp_dicts) == len(ref_dicts)
@@ -355,7 +383,7 @@ def test_error_behaviour(pp, engines):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"PP_GEMM_PREC": "f32"}, {"PP_GEMM_PREC": "f32", "PP_SEP_KERNEL": "ws"},
                                  {"PP_PFN_KERNEL": "1"}, {"PP_NO_HEAD_FUSION": "1"},
-                                 {"PP_NO_GRAPH": "1", "PP_SEP_NT": "64"}])
+                                 {"PP_NO_GRAPH": "1", "PP_SEP_NT": "64"}, {"PP_SEP_K4": "0"}])
 def test_fallback_kernel_generations_stay_in_parity(hip_lib, env):
     """The earlier kernel generations are selectable at process start (fp32-MFMA instantiations, the
     producer/consumer GEMM, the first PFN); one child process per selection runs the whole path on two
