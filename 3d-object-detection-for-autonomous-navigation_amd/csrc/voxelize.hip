@@ -96,11 +96,14 @@ int voxel_sort_passes(int max_voxels) {
     return (bits + 7) / 8;
 }
 
+// BITS: digit width of the radix passes as a compile-time constant (the ballot loops unroll), 0 = run time
+template <int BITS>
 __global__ __launch_bounds__(VT) void k_voxel_frame(
     const int* __restrict__ offsets, const int* __restrict__ cell, const int* __restrict__ first,
     int* __restrict__ cellmap, unsigned* keyA, unsigned* idxA, unsigned* keyB, unsigned* idxB,
     int* __restrict__ pillar_start, int* __restrict__ pillar_cell, int* __restrict__ npillars,
-    int* __restrict__ nvalid_out, int ncell, int max_voxels, int npass, int bits) {
+    int* __restrict__ nvalid_out, int ncell, int max_voxels, int npass, int bits_rt) {
+    const int bits = (BITS > 0) ? BITS : bits_rt;
     __shared__ int s_tot[VWAVES];
     __shared__ int s_carry;
     __shared__ int s_break;
@@ -130,7 +133,15 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
     // and the (pillar id, point index) pairs are packed into one 32-bit word and radix-sorted in LDS. ----
     int ib = 1;
     while ((1 << ib) < n) ++ib;                 // bits of a point index
-    if (n <= VL_CAP && npass * bits + ib <= 32 && (first != nullptr || ncell <= 2 * VL_CAP)) {
+#ifdef PP_VOX_STAMPS   // diagnostic build: phase times of frame 0 (100 MHz ticks), printed by thread 0
+    long long vst[12];
+    int vsn = 0;
+#define V_STAMP() { if (vsn < 12) vst[vsn++] = wall_clock64(); }
+#else
+#define V_STAMP() {}
+#endif
+    V_STAMP()
+    if (n <= VL_CAP && npass * bits + ib <= 32 && (first != nullptr || ncell <= VL_CAP)) {
         const int ppt = (n + VT - 1) / VT;      // <= VL_PPT
         const int i0 = tid * ppt;
         int c[VL_PPT];
@@ -143,7 +154,9 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
         } else {
             // first point index of every cell by LDS atomics (the sort buffers are not in use yet): no global
             // atomics, whose same-address traffic on crowded cells serialises across the chip
-            int* s_first = reinterpret_cast<int*>(s_sort);
+            // (upper half of the sort buffers: it stays intact until the first sort pass scatters into it, and
+            // carries the cell -> pillar id map after the first-point indices have been consumed)
+            int* s_first = reinterpret_cast<int*>(s_sort) + VL_CAP;
             for (int e = tid; e < ncell; e += VT) s_first[e] = 0x7fffffff;
             __syncthreads();
 #pragma unroll
@@ -153,6 +166,8 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
             for (int k = 0; k < VL_PPT; ++k) f[k] = (c[k] >= 0) ? s_first[c[k]] : -1;
             __syncthreads();   // s_sort is written below
         }
+        V_STAMP()   // 1: cells loaded, first-of-cell known
+        int* const s_map = reinterpret_cast<int*>(s_sort) + VL_CAP;   // cell -> pillar id (LDS copy of fmap)
         unsigned flags = 0;
 #pragma unroll
         for (int k = 0; k < VL_PPT; ++k) if (c[k] >= 0 && f[k] == i0 + k) flags |= 1u << k;
@@ -166,6 +181,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
                     const int pid = basep + r++;
                     if (pid < max_voxels) {
                         fmap[c[k]] = pid;
+                        if (first == nullptr) s_map[c[k]] = pid;
                         pillar_cell[(size_t)b * max_voxels + pid] = c[k];
                     } else if (pid == max_voxels) {
                         s_break = i0 + k;       // exactly one point has this prefix
@@ -173,6 +189,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
                 }
         }
         __syncthreads();                        // cell map of this frame + break point visible to the block
+        V_STAMP()   // 2: pillar ids assigned, cell map written
         const int P = min(totp, max_voxels);
         const int ibreak = s_break;
         unsigned vmask = 0;
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
         for (int k = 0; k < VL_PPT; ++k) if (c[k] >= 0 && i0 + k < ibreak) vmask |= 1u << k;
         int key[VL_PPT];
 #pragma unroll
-        for (int k = 0; k < VL_PPT; ++k) key[k] = ((vmask >> k) & 1u) ? fmap[c[k]] : 0;
+        for (int k = 0; k < VL_PPT; ++k) key[k] = ((vmask >> k) & 1u) ? (first == nullptr ? s_map[c[k]] : fmap[c[k]]) : 0;
         int nv;
         const int basev = block_excl_scan(__popc(vmask), s_tmp, nv);
         {
@@ -190,6 +207,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
                 if ((vmask >> k) & 1u) s_sort[basev + r++] = ((unsigned)key[k] << ib) | (unsigned)(i0 + k);
         }
         __syncthreads();
+        V_STAMP()   // 3: keys fetched, compaction done
         // stable LSD radix sort of the packed words by pillar id, LDS to LDS
         unsigned* sk = s_sort;
         unsigned* dk = s_sort + VL_CAP;
@@ -197,14 +215,50 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
         const unsigned dmask = (unsigned)NB - 1u;
         const int chunk = ((nv + VWAVES * 64 - 1) / (VWAVES * 64)) * 64;
         const int wbeg = min(wave * chunk, nv), wend = min(wbeg + chunk, nv);
-        volatile int* vhist = s_hist;
+        // A wave sorts its contiguous chunk (<= VL_PPT steps of 64 elements, held in registers for the pass).
+        // Histogram step: the lanes that share a digit find each other by digit-bit ballots; each reads the
+        // wave's running count of that digit (= how many earlier elements of the chunk carry it) and one of
+        // them adds the group size -- conflict-free LDS operations that execute in issue order, so the 16
+        // steps pipeline without a wait.  After the block-wide scan of the (digit, wave) counts the target
+        // position of every element is known: no serial chain in the scatter.
         for (int pass = 0; pass < npass; ++pass) {
             const int shift = ib + pass * bits;
             for (int e = tid; e < NB * VWAVES; e += VT) s_hist[e] = 0;
+            unsigned ev[VL_PPT];
+#pragma unroll
+            for (int t = 0; t < VL_PPT; ++t) {
+                const int j = wbeg + t * 64 + lane;
+                ev[t] = (j < wend) ? sk[j] : 0u;
+            }
             __syncthreads();
-            for (int t0 = wbeg; t0 < wend; t0 += 64) {
-                const int j = t0 + lane;
-                if (j < wend) atomicAdd(&s_hist[((sk[j] >> shift) & dmask) * VWAVES + wave], 1);
+            int rank[VL_PPT];
+#pragma unroll
+            for (int t = 0; t < VL_PPT; ++t) {
+                rank[t] = 0;
+                if (wbeg + t * 64 < wend) {                     // wave-uniform
+                    const bool act = wbeg + t * 64 + lane < wend;
+                    const unsigned d = (ev[t] >> shift) & dmask;
+                    unsigned long long peers = __ballot(act);
+                    if (BITS > 0) {
+#pragma unroll
+                        for (int bit = 0; bit < BITS; ++bit) {
+                            const bool one = (d >> bit) & 1u;
+                            const unsigned long long bb = __ballot(act && one);
+                            peers &= one ? bb : ~bb;
+                        }
+                    } else {
+                        for (int bit = 0; bit < bits; ++bit) {
+                            const bool one = (d >> bit) & 1u;
+                            const unsigned long long bb = __ballot(act && one);
+                            peers &= one ? bb : ~bb;
+                        }
+                    }
+                    if (act) {
+                        int* hp = &s_hist[d * VWAVES + wave];
+                        rank[t] = *reinterpret_cast<volatile int*>(hp) + __popcll(peers & lt);
+                        if ((peers & lt) == 0ull) atomicAdd(hp, __popcll(peers));   // lowest lane of the group
+                    }
+                }
             }
             __syncthreads();
             {
@@ -220,24 +274,15 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
                     if (e0 + q < E) { int t = s_hist[e0 + q]; s_hist[e0 + q] = run; run += t; }
             }
             __syncthreads();
-            for (int t0 = wbeg; t0 < wend; t0 += 64) {
-                const int j = t0 + lane;
-                const bool act = j < wend;
-                const unsigned v = act ? sk[j] : 0u;
-                const unsigned d = (v >> shift) & dmask;
-                unsigned long long peers = __ballot(act);
-                for (int bit = 0; bit < bits; ++bit) {
-                    const bool one = (d >> bit) & 1u;
-                    const unsigned long long bb = __ballot(act && one);
-                    peers &= one ? bb : ~bb;
-                }
-                if (act) {
-                    const int basepos = vhist[d * VWAVES + wave];
-                    dk[basepos + __popcll(peers & lt)] = v;
-                    if (lane == 63 - __clzll(peers)) vhist[d * VWAVES + wave] = basepos + __popcll(peers);
+#pragma unroll
+            for (int t = 0; t < VL_PPT; ++t) {
+                if (wbeg + t * 64 + lane < wend) {
+                    const unsigned d = (ev[t] >> shift) & dmask;
+                    dk[s_hist[d * VWAVES + wave] + rank[t]] = ev[t];
                 }
             }
             __syncthreads();
+            V_STAMP()   // 4, 5: sort passes
             unsigned* t = sk; sk = dk; dk = t;
         }
         // sorted point indices + CSR row starts
@@ -255,6 +300,15 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
             npillars[b] = P;
             nvalid_out[b] = nv;
         }
+#ifdef PP_VOX_STAMPS
+        __syncthreads();
+        V_STAMP()
+        if (tid == 0 && b == 0) {
+            printf("vox n=%d nv=%d:", n, nv);
+            for (int q = 1; q < vsn; ++q) printf(" %d", (int)(vst[q] - vst[q - 1]));
+            printf("\n");
+        }
+#endif
         return;
     }
 
@@ -437,7 +491,7 @@ bool voxel_first_in_lds(int max_n, int ncell, int max_voxels) {
     while ((1 << ib) < max_n) ++ib;
     const int npass = (kb + 7) / 8;
     const int bits = (kb + npass - 1) / npass;
-    return max_n <= VL_CAP && ncell <= 2 * VL_CAP && npass * bits + ib <= 32;
+    return max_n <= VL_CAP && ncell <= VL_CAP && npass * bits + ib <= 32;
 }
 
 void launch_cell_first(const float* pts, const int* offsets, int batch, int max_n, int F, const VoxGeom& g,
@@ -455,8 +509,12 @@ void launch_voxel_frame(const int* offsets, const int* cell, const int* first, i
     while ((1 << kb) < max_voxels) ++kb;
     const int npass = (kb + 7) / 8;
     const int bits = (kb + npass - 1) / npass;
-    hipLaunchKernelGGL(k_voxel_frame, dim3(batch), dim3(VT), 0, s, offsets, cell, first, cellmap, keyA, idxA, keyB,
-                       idxB, pillar_start, pillar_cell, npillars, nvalid, ncell, max_voxels, npass, bits);
+    if (bits == 7)   // 8193..16384 pillars (the shipped configuration): unrolled digit loops
+        hipLaunchKernelGGL(k_voxel_frame<7>, dim3(batch), dim3(VT), 0, s, offsets, cell, first, cellmap, keyA, idxA, keyB,
+                           idxB, pillar_start, pillar_cell, npillars, nvalid, ncell, max_voxels, npass, bits);
+    else
+        hipLaunchKernelGGL(k_voxel_frame<0>, dim3(batch), dim3(VT), 0, s, offsets, cell, first, cellmap, keyA, idxA, keyB,
+                           idxB, pillar_start, pillar_cell, npillars, nvalid, ncell, max_voxels, npass, bits);
 }
 
 void launch_voxel_expand(const float* pts, const int* offsets, const unsigned* sorted_idx, const int* pillar_start,
