@@ -50,7 +50,15 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     __shared__ int s_keep[KMAX];
     __shared__ int s_nkeep;
 
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+#ifdef PP_POST_STAMPS   // diagnostic build: phase times of frame 0 (100 MHz ticks), printed by thread 0
+    long long pst[24];
+    int psn = 0;
+#define P_STAMP() { if (psn < 24) pst[psn++] = wall_clock64(); }
+#else
+#define P_STAMP() {}
+#endif
+    P_STAMP()
     const long long A = p.A;
     const int napl = p.napl;
     const int nb = napl * 7, nc = napl;
@@ -77,23 +85,20 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     // ---- candidates -> LDS once (the head map is read a single time; the select passes run on LDS) ----
     if (tid == 0) { s_prefix = 0ull; s_need = KTOP; s_shift = 56; s_done = 0; s_cnt = 0; s_ncand = 0; }
     __syncthreads();
-    // (8 anchors per thread at a time: the mask bytes, then the logits, are loaded together -- two memory
-    // round trips per 8192 anchors instead of two per 1024)
-    for (long long a0 = tid; a0 < A; a0 += 8 * PT) {
-        uint8_t mk[8];
-        float lgs[8];
+    // (16 anchors per thread at a time; the logit loads do not wait for the mask bytes -- nearly every anchor
+    // is a candidate -- so a frame of up to 16 384 anchors costs one memory round trip)
+    for (long long ab = 0; ab < A; ab += 16 * PT) {
+        const long long a0 = ab + tid;
+        uint8_t mk[16];
+        float lgs[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 16; ++k) {
             const long long a = a0 + (long long)k * PT;
             mk[k] = (a < A) ? msk[a] : (uint8_t)0;
+            lgs[k] = (a < A) ? cls_of(a) : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const long long a = a0 + (long long)k * PT;
-            lgs[k] = (mk[k] == 1) ? cls_of(a) : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 16; ++k) {
             if (mk[k] != 1) continue;
             if (thr > 0.f) {
                 const float sc = 1.f / (1.f + expf(-lgs[k]));
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         }
     }
     __syncthreads();
+    P_STAMP()   // candidates gathered
     const int ncand = s_ncand;
     const bool in_lds = ncand <= CCAP;
 
@@ -172,8 +178,10 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
             }
         }
         __syncthreads();
+        P_STAMP()   // one select pass
     }
     __syncthreads();
+    P_STAMP()
     {
         const int shift = s_shift;
         const unsigned long long prefix = s_prefix;
@@ -198,6 +206,7 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         }
     }
     __syncthreads();
+    P_STAMP()   // selected keys collected
     const int K = min(s_cnt, KTOP);
     // ---- order by descending key (rank by counting; keys are unique) ----
     if (tid < K) {
@@ -207,6 +216,7 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         s_order[rank] = tid;
     }
     __syncthreads();
+    P_STAMP()   // ordered
 
     // ---- decode + stand-up AABB (float32, the reference's operation order) ----
     if (tid < K) {
@@ -250,47 +260,78 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         s_aabb[tid][0] = x0; s_aabb[tid][1] = y0; s_aabb[tid][2] = x1; s_aabb[tid][3] = y1;
     }
     __syncthreads();
+    P_STAMP()   // decoded
 
     // ---- NMS over the first min(K, pre_max) boxes (already score-descending) ----
+    // suppression masks: 8 threads share a row i and take every 8th j > i (the float64 division keeps
+    // iou_device's arithmetic); their partial masks meet in LDS
     const int n = min(K, p.pre_max);
-    if (tid < n) {
-        unsigned long long m0 = 0ull, m1 = 0ull;
-        const float ax0 = s_aabb[tid][0], ay0 = s_aabb[tid][1], ax1 = s_aabb[tid][2], ay1 = s_aabb[tid][3];
-        const double sa = ((double)(ax1 - ax0) + 1.0) * ((double)(ay1 - ay0) + 1.0);
-        const double dthr = (double)p.iou_thr;
-        for (int j = tid + 1; j < n; ++j) {
-            const float bx0 = s_aabb[j][0], by0 = s_aabb[j][1], bx1 = s_aabb[j][2], by1 = s_aabb[j][3];
-            const float left = fmaxf(ax0, bx0), right = fminf(ax1, bx1);
-            const float top = fmaxf(ay0, by0), bottom = fminf(ay1, by1);
-            const float dw = right - left, dh = bottom - top;   // float32 differences
-            const double w = fmax((double)dw + 1.0, 0.0);
-            const double hh = fmax((double)dh + 1.0, 0.0);
-            const double inter = w * hh;
-            const double sb = ((double)(bx1 - bx0) + 1.0) * ((double)(by1 - by0) + 1.0);
-            const double iou = inter / (sa + sb - inter);
-            if (iou > dthr) {
-                if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64);
+    if (tid < 2 * KMAX) reinterpret_cast<unsigned long long*>(s_mask)[tid] = 0ull;
+    __syncthreads();
+    {
+        const int row = tid >> 3, sub = tid & 7;
+        if (row < n) {
+            unsigned long long m0 = 0ull, m1 = 0ull;
+            const float ax0 = s_aabb[row][0], ay0 = s_aabb[row][1], ax1 = s_aabb[row][2], ay1 = s_aabb[row][3];
+            const double sa = ((double)(ax1 - ax0) + 1.0) * ((double)(ay1 - ay0) + 1.0);
+            const double dthr = (double)p.iou_thr;
+            for (int j = row + 1 + sub; j < n; j += 8) {
+                const float bx0 = s_aabb[j][0], by0 = s_aabb[j][1], bx1 = s_aabb[j][2], by1 = s_aabb[j][3];
+                const float left = fmaxf(ax0, bx0), right = fminf(ax1, bx1);
+                const float top = fmaxf(ay0, by0), bottom = fminf(ay1, by1);
+                const float dw = right - left, dh = bottom - top;   // float32 differences
+                const double w = fmax((double)dw + 1.0, 0.0);
+                const double hh = fmax((double)dh + 1.0, 0.0);
+                const double inter = w * hh;
+                const double sb = ((double)(bx1 - bx0) + 1.0) * ((double)(by1 - by0) + 1.0);
+                const double iou = inter / (sa + sb - inter);
+                if (iou > dthr) {
+                    if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64);
+                }
             }
+            if (m0) atomicOr(&s_mask[row][0], m0);
+            if (m1) atomicOr(&s_mask[row][1], m1);
         }
-        s_mask[tid][0] = m0;
-        s_mask[tid][1] = m1;
     }
     __syncthreads();
-    if (tid == 0) {
+    P_STAMP()   // pair masks
+    // greedy sweep by wave 0: lane l holds the mask rows l and l + 64 in registers; the kept boxes are walked
+    // with find-first-set over "not yet visited and not removed" (scalar), a kept row's mask comes by readlane
+    if (tid < 64) {
+        const unsigned long long a0 = (lane < n) ? s_mask[lane][0] : 0ull, a1 = (lane < n) ? s_mask[lane][1] : 0ull;
+        const unsigned long long b0 = (lane + 64 < n) ? s_mask[lane + 64][0] : 0ull;
+        const unsigned long long b1 = (lane + 64 < n) ? s_mask[lane + 64][1] : 0ull;
+        auto rdl = [](unsigned long long v, int l) -> unsigned long long {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), l);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+            return ((unsigned long long)hi << 32) | lo;
+        };
+        unsigned long long todo0 = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+        unsigned long long todo1 = (n <= 64) ? 0ull : ((n - 64 >= 64) ? ~0ull : ((1ull << (n - 64)) - 1ull));
         unsigned long long r0 = 0ull, r1 = 0ull;
-        int nk = 0;
-        for (int i = 0; i < n && nk < p.post_max; ++i) {
-            const bool removed = (i < 64) ? ((r0 >> i) & 1ull) : ((r1 >> (i - 64)) & 1ull);
-            if (!removed) {
-                s_keep[nk++] = i;
-                r0 |= s_mask[i][0];
-                r1 |= s_mask[i][1];
+        int nk = 0, k0 = 0, k1 = 0;
+        while (nk < p.post_max) {
+            const unsigned long long c0 = todo0 & ~r0, c1 = todo1 & ~r1;
+            if ((c0 | c1) == 0ull) break;
+            int i = c0 ? __builtin_ctzll(c0) : 64 + __builtin_ctzll(c1);
+            i = __builtin_amdgcn_readfirstlane(i);
+            if (lane == (nk & 63)) { if (nk < 64) k0 = i; else k1 = i; }   // lane l remembers kept boxes l and l + 64
+            ++nk;
+            if (i < 64) {
+                todo0 &= ~((2ull << i) - 1ull);       // i = 63: 2 << 63 wraps to 0, minus 1 = all ones
+                r0 |= rdl(a0, i); r1 |= rdl(a1, i);
+            } else {
+                todo0 = 0ull;
+                todo1 &= ~((2ull << (i - 64)) - 1ull);
+                r0 |= rdl(b0, i - 64); r1 |= rdl(b1, i - 64);
             }
         }
-        s_nkeep = nk;
-        p.n_dets[b] = nk;
+        if (lane < nk) s_keep[lane] = k0;
+        if (lane + 64 < nk) s_keep[lane + 64] = k1;
+        if (lane == 0) { s_nkeep = nk; p.n_dets[b] = nk; }
     }
     __syncthreads();
+    P_STAMP()   // sweep
 
     // ---- direction flip + lidar -> camera, in keep (descending score) order ----
     const int nk = s_nkeep;
@@ -319,6 +360,15 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         o->anchor_index = s_anchor[i];
         o->reserved = 0;
     }
+#ifdef PP_POST_STAMPS
+    __syncthreads();
+    P_STAMP()
+    if (tid == 0 && b == 0) {
+        printf("post ncand=%d K=%d nk=%d:", ncand, K, nk);
+        for (int q = 1; q < psn; ++q) printf(" %d", (int)(pst[q] - pst[q - 1]));
+        printf("\n");
+    }
+#endif
 }
 
 void launch_postprocess(const PostParams& p, hipStream_t s) {
