@@ -1471,6 +1471,235 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
 #undef D_FILL_OPIX
 }
 
+// ---------------------------------------------------------------------------------------
+// Split-K Conv2DTranspose (+ fused heads) for small maps: the four waves of a workgroup share one
+// 32-pixel x NT tile and take every fourth K-chunk each (private weight tiles, no barrier inside the K
+// loop; the input fragments of all of a wave's chunks are loaded up front).  The partial accumulators meet
+// in LDS (fixed order of addition), wave n finishes channel tile n -- bias, ReLU, concat slice if it is
+// kept, its 32 channels' share of the head GEMM -- and wave 0 adds the head shares to the head bias / the
+// earlier branches' sums.  Same operand layout as k_deconv_u (accumulator = out^T, heads from registers).
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
+    constexpr int KCH = 16;
+    constexpr int NTILES = NT / 32;
+    constexpr int SB = 3 * NT * 8;                       // one weight tile: [3 pieces][NT][8 floats]
+    constexpr int NBL = NT * 6 / 64;                     // 16-byte weight items per lane per chunk
+    constexpr int SHW = (NT / 16) * 3 * 32 * 8;
+    constexpr int SLOT = 16 * 64;                        // one partial accumulator tile (floats)
+    constexpr int OWNERS = NTILES < 4 ? NTILES : 4;
+    static_assert((4 * NTILES - OWNERS) * SLOT <= 4 * SB, "partial sums overlay the weight tiles");
+    __shared__ __attribute__((aligned(16))) float sR[4 * SB];
+    __shared__ __attribute__((aligned(16))) float sHW[SHW];
+    __shared__ float s_bias[NT];
+    __shared__ float s_hbias[PP_HEAD_COLS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, r32 = lane & 31;
+    const int n0 = blockIdx.y * NT;
+    const int cin = a.cin;
+    const int niter = cin / (KCH * 4);                   // chunks per wave: 1..4 (checked by the launcher)
+    const int tap = n0 / a.cout, cbase = n0 - tap * a.cout;
+    const int ti = tap / a.k;
+    const int delta = ti * (a.px_w * a.k) + (tap - ti * a.k);
+    const bool heads = a.head_mode != 0;
+    float* const sBw = sR + wave * SB;
+
+    if (tid < NT) s_bias[tid] = a.bias[cbase + tid];
+    if (heads) {
+        for (int e = tid; e < SHW / 4; e += 256)
+            reinterpret_cast<float4*>(sHW)[e ^ ((e >> 4) & 1)] = reinterpret_cast<const float4*>(a.head_wt16)[e];
+        if (tid < PP_HEAD_COLS) s_hbias[tid] = a.head_bias[tid];
+    }
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt16);
+    const int pix = blockIdx.x * 32 + r32;
+    const bool ok = pix < a.M;
+    const unsigned avo = ok ? (unsigned)(pix * cin + h * 8) * 4u + PP_ZPAD_FLOATS * 4u : (unsigned)(h * 32);
+    // all input fragments of this wave's chunks: one memory round trip
+    float4 ra[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ra[j][0] = ra[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < niter) {
+            const unsigned so = (unsigned)(wave + 4 * j) * (KCH * 4);
+            ra[j][0] = buf_load16(rs_in, avo, so);
+            ra[j][1] = buf_load16(rs_in, avo + 16u, so);
+        }
+    }
+    unsigned boff[NBL];
+    int bdst[NBL];
+#pragma unroll
+    for (int r = 0; r < NBL; ++r) {
+        const int e = lane + 64 * r;
+        const int piece = e / (NT * 2), rem = e % (NT * 2), row = rem >> 1, half = rem & 1;
+        boff[r] = (unsigned)(((piece * a.n_total + n0 + row) * 16 + half * 8) * 2);
+        bdst[r] = piece * (NT * 8) + row * 8 + ((half ^ ((row >> 3) & 1)) * 4);
+    }
+    const unsigned bstep = (unsigned)(3 * a.n_total * 32);
+    float4 rb[NBL];
+#pragma unroll
+    for (int r = 0; r < NBL; ++r) rb[r] = buf_load16(rs_wt, boff[r], (unsigned)wave * bstep);
+    f32x16 acc[NTILES];
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const float* const cB = sBw + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < niter) {                                 // uniform
+            // weight tile of chunk j -> this wave's LDS tile (a wave's LDS operations execute in order: the
+            // previous chunk's fragment reads were issued before these writes)
+#pragma unroll
+            for (int r = 0; r < NBL; ++r) *reinterpret_cast<float4*>(sBw + bdst[r]) = rb[r];
+            if (j + 1 < niter) {
+#pragma unroll
+                for (int r = 0; r < NBL; ++r) rb[r] = buf_load16(rs_wt, boff[r], (unsigned)(wave + 4 * (j + 1)) * bstep);
+            }
+            const float av[8] = {ra[j][0].x, ra[j][0].y, ra[j][0].z, ra[j][0].w, ra[j][1].x, ra[j][1].y, ra[j][1].z, ra[j][1].w};
+            bf16x8 ah, am, al;
+            split_bf16x3(av, ah, am, al);
+#pragma unroll
+            for (int n = 0; n < NTILES; ++n) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm, am, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, am, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm, ah, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[n], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial sums: every tile a wave does not own goes to LDS ----
+    // slot of (source wave w, tile n), n != w, in row-major order with the owners' own tiles left out
+    auto slot = [](int w, int n) -> int {
+        return w * NTILES + n - (w < OWNERS ? w : OWNERS) - ((w < OWNERS && n > w) ? 1 : 0);
+    };
+    __syncthreads();   // all waves are done with their weight tiles (and bias / head weights are visible)
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+        if (n != wave) {
+            float* d = sR + slot(wave, n) * SLOT + lane * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(d + g * 256) = make_float4(acc[n][4 * g], acc[n][4 * g + 1], acc[n][4 * g + 2], acc[n][4 * g + 3]);
+        }
+    __syncthreads();
+    // output pixel of this lane's input pixel
+    const int pc = ok ? pix : 0;
+    const int hwpx = a.px_h * a.px_w;
+    const int pb = pc / hwpx, prem = pc - pb * hwpx;
+    const int py = prem / a.px_w, pxx = prem - py * a.px_w;
+    const size_t orow = (size_t)((pb * a.px_h * a.k + py * a.k) * (a.px_w * a.k) + pxx * a.k + delta);
+    f32x16 hpart;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hpart[r] = 0.f;
+    if (wave < NTILES) {
+        // own partial first, then the other waves' in ascending order: a fixed order of addition
+        float v[16];
+#pragma unroll
+        for (int n = 0; n < NTILES; ++n)
+            if (n == wave) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[n][r];
+            }
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            if (w != wave) {
+                const float* sp = sR + slot(w, wave) * SLOT + lane * 4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t = *reinterpret_cast<const float4*>(sp + g * 256);
+                    v[4 * g] += t.x; v[4 * g + 1] += t.y; v[4 * g + 2] += t.z; v[4 * g + 3] += t.w;
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r] + s_bias[wave * 32 + DCH(r, h)], 0.f);
+        if (a.out != nullptr && ok) {
+            float* dst = a.out + orow * a.ld_out + a.co_off + cbase + 4 * h + wave * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        }
+        if (heads) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float av[8] = {v[8 * g], v[8 * g + 1], v[8 * g + 2], v[8 * g + 3],
+                                     v[8 * g + 4], v[8 * g + 5], v[8 * g + 6], v[8 * g + 7]};
+                bf16x8 xh, xm, xl;
+                split_bf16x3(av, xh, xm, xl);
+                const float* hW = sHW + ((wave * 2 + g) * 3 * 32 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(hW);
+                const bf16x8 wm = *reinterpret_cast<const bf16x8*>(hW + 32 * 8);
+                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(hW + 2 * 32 * 8);
+                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, hpart, 0, 0, 0);
+                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, hpart, 0, 0, 0);
+                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, hpart, 0, 0, 0);
+                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, hpart, 0, 0, 0);
+                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, hpart, 0, 0, 0);
+                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, hpart, 0, 0, 0);
+            }
+        }
+    }
+    if (!heads) return;                                  // uniform
+    __syncthreads();   // the partial-sum slots have been read
+    if (wave >= 1 && wave < NTILES) {
+        float* d = sR + (wave - 1) * SLOT + lane * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(d + g * 256) = make_float4(hpart[4 * g], hpart[4 * g + 1], hpart[4 * g + 2], hpart[4 * g + 3]);
+    }
+    __syncthreads();
+    if (wave == 0 && ok) {
+        // head row of this pixel: this lane owns columns 4h + {0..3, 8..11, 16..19, 24..27}
+        float* hrow = a.head + orow * PP_HEAD_COLS + 4 * h;
+        float hv[16];
+        if (a.head_mode == 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(hrow + 8 * g);
+                hv[4 * g] = t.x; hv[4 * g + 1] = t.y; hv[4 * g + 2] = t.z; hv[4 * g + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[r] = s_hbias[DCH(r, h)];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] += hpart[r];
+#pragma unroll
+        for (int w = 1; w < NTILES; ++w) {
+            const float* sp = sR + (w - 1) * SLOT + lane * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(sp + g * 256);
+                hv[4 * g] += t.x; hv[4 * g + 1] += t.y; hv[4 * g + 2] += t.z; hv[4 * g + 3] += t.w;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(hrow + 8 * g) = make_float4(hv[4 * g], hv[4 * g + 1], hv[4 * g + 2], hv[4 * g + 3]);
+    }
+}
+
+// runs while the layer has at most 1.5 workgroups per CU (measured crossover against k_deconv_u on cfg-A,
+// tools/k4_sweep.sh: ahead at B = 1, 2 (160 / 320 workgroups), behind from B = 4); PP_DECONV_K4=0: never,
+// =n: up to n per CU
+static bool deconv_k4_runs(const LayerDesc& L, long long M, int ablate) {
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("PP_DECONV_K4"); force = e ? atoi(e) : -1; }
+    if (force == 0 || (ablate & 16) || L.cin % 64 != 0 || L.cin > 256) return false;
+    const int nt = L.cout % 128 == 0 ? 128 : (L.cout % 64 == 0 ? 64 : 32);
+    const int half_cus = force > 0 ? 2 * force : 3;
+    return 2 * ((M + 31) / 32 * (L.n_total / nt)) <= (long long)half_cus * g_num_cus;
+}
+template <int NT>
+static void launch_deconv_k4(const GemmArgs& a, int n_total, hipStream_t s) {
+    dim3 grid((unsigned)((a.M + 31) / 32), n_total / NT);
+    hipLaunchKernelGGL((k_deconv_k4<NT>), grid, dim3(256), 0, s, a);
+}
+
 template <int NT>
 static void launch_deconv_u(const GemmArgs& a, int n_total, hipStream_t s) {
     constexpr int WPS = 3;
@@ -1587,6 +1816,8 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
         if (L.stride == 1) wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 3 : 4);
         else wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 2 : (unt == 64 ? 3 : 4));
         snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d,%d>", unt, L.stride, wps, bf ? 1 : 0);
+    } else if (deconv_uniform(L, 0) && deconv_k4_runs(L, layer_rows(L, batch), 0)) {
+        snprintf(buf, sizeof(buf), "k_deconv_k4<%d>", nt);
     } else if (deconv_uniform(L, 0)) {
         snprintf(buf, sizeof(buf), "k_deconv_u<%d,3>", nt);
     } else if (use_ws(L)) {
@@ -1653,7 +1884,11 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
         a.px_h = L.in_h; a.px_w = L.in_w; a.epi = 1;
         a.M = batch * L.in_h * L.in_w;
         if (L.cout % 32 != 0) return PP_ERR_UNSUPPORTED;
-        if (deconv_uniform(L, ablate)) {
+        if (deconv_uniform(L, ablate) && deconv_k4_runs(L, a.M, ablate)) {   // small map: split-K
+            if (L.cout % 128 == 0) launch_deconv_k4<128>(a, L.n_total, s);
+            else if (L.cout % 64 == 0) launch_deconv_k4<64>(a, L.n_total, s);
+            else launch_deconv_k4<32>(a, L.n_total, s);
+        } else if (deconv_uniform(L, ablate)) {
             if (L.cout % 128 == 0) launch_deconv_u<128>(a, L.n_total, s);
             else if (L.cout % 64 == 0) launch_deconv_u<64>(a, L.n_total, s);
             else launch_deconv_u<32>(a, L.n_total, s);

@@ -153,7 +153,7 @@ def test_small_map_split_k_kernel_ragged_tiles(pp, engines):
     d = eng.d
     assert (d.nx, d.ny) == (28, 20)
     tags = eng.layer_tags()
-    assert any(t.startswith("k_sep_k4") for t in tags), tags
+    assert any(t.startswith("k_sep_k4") for t in tags) and any(t.startswith("k_deconv_k4") for t in tags), tags
     w = util_ref.scale_heads(pp.weights.init_weights(d, seed=11))
     rng = np.random.default_rng(21)
     frames = [rng.uniform([0, -0.8, -3], [2.24, 0.8, 3], (n, 3)).astype(np.float32) for n in (3000, 1700)]
@@ -383,7 +383,7 @@ def test_error_behaviour(pp, engines):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"PP_GEMM_PREC": "f32"}, {"PP_GEMM_PREC": "f32", "PP_SEP_KERNEL": "ws"},
                                  {"PP_PFN_KERNEL": "1"}, {"PP_NO_HEAD_FUSION": "1"},
-                                 {"PP_NO_GRAPH": "1", "PP_SEP_NT": "64"}, {"PP_SEP_K4": "0"}])
+                                 {"PP_NO_GRAPH": "1", "PP_SEP_NT": "64"}, {"PP_SEP_K4": "0", "PP_DECONV_K4": "0"}])
 def test_fallback_kernel_generations_stay_in_parity(hip_lib, env):
     """The earlier kernel generations are selectable at process start (fp32-MFMA instantiations, the
     producer/consumer GEMM, the first PFN); one child process per selection runs the whole path on two
