@@ -252,12 +252,9 @@ int run_voxelize(pp_engine* e, int batch, int max_n) {
         HIPCHK(e, hipMemsetAsync(e->d_first, 0x7f, (size_t)batch * e->ncell * sizeof(int), e->stream));
     }
     {
-        ProfScope ps(e, "memset_cellmap");
-        HIPCHK(e, hipMemsetAsync(e->d_cellmap, 0xff, (size_t)batch * e->ncell * sizeof(int), e->stream));
-    }
-    {
-        ProfScope ps(e, "k_cell_first");
-        launch_cell_first(e->d_points, e->d_offsets, batch, max_n, e->F, e->geom, e->d_cell, d_first, e->stream);
+        ProfScope ps(e, "k_cell_first");   // also clears the cell map
+        launch_cell_first(e->d_points, e->d_offsets, batch, max_n, e->F, e->geom, e->d_cell, d_first, e->d_cellmap,
+                          e->stream);
     }
     {
         ProfScope ps(e, "k_voxel_frame");

@@ -55,7 +55,7 @@ struct LayerDesc {
 
 // ----- launchers (each in its own .hip file) ----------------------------
 void launch_cell_first(const float* pts, const int* offsets, int batch, int max_n, int F, const VoxGeom& g,
-                       int* cell, int* first, hipStream_t s);
+                       int* cell, int* first, int* cellmap, hipStream_t s);
 // returns (through *sorted_in_b) nothing; the host derives the final buffer from voxel_sort_passes()
 int voxel_sort_passes(int max_voxels);
 bool voxel_first_in_lds(int max_n, int ncell, int max_voxels);   // pass first = NULL to both launchers below

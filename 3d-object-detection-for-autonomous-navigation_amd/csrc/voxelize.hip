@@ -41,8 +41,13 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 
 __global__ __launch_bounds__(256) void k_cell_first(const float* __restrict__ pts,
                                                     const int* __restrict__ offsets, int F, VoxGeom g,
-                                                    int* __restrict__ cell, int* __restrict__ first) {
+                                                    int* __restrict__ cell, int* __restrict__ first,
+                                                    int* __restrict__ cellmap) {
     const int b = blockIdx.y;
+    // this frame's cell -> pillar map is cleared here (-1 = empty; k_voxel_frame, next in the stream, is the
+    // first to write it): one launch less than a separate memset node
+    if (cellmap != nullptr)
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < g.ncell; e += gridDim.x * 256) cellmap[(size_t)b * g.ncell + e] = -1;
     const int n0 = offsets[b];
     const int n = offsets[b + 1] - n0;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -495,10 +500,10 @@ bool voxel_first_in_lds(int max_n, int ncell, int max_voxels) {
 }
 
 void launch_cell_first(const float* pts, const int* offsets, int batch, int max_n, int F, const VoxGeom& g,
-                       int* cell, int* first, hipStream_t s) {
-    if (max_n <= 0 || batch <= 0) return;
-    dim3 grid((max_n + 255) / 256, batch);
-    hipLaunchKernelGGL(k_cell_first, grid, dim3(256), 0, s, pts, offsets, F, g, cell, first);
+                       int* cell, int* first, int* cellmap, hipStream_t s) {
+    if (batch <= 0) return;
+    dim3 grid(max_n > 0 ? (max_n + 255) / 256 : 1, batch);   // at least one block per frame: it clears the cell map
+    hipLaunchKernelGGL(k_cell_first, grid, dim3(256), 0, s, pts, offsets, F, g, cell, first, cellmap);
 }
 
 void launch_voxel_frame(const int* offsets, const int* cell, const int* first, int* cellmap, unsigned* keyA,
