@@ -205,17 +205,12 @@ def main():
     agg, per_layer = {}, {}
     prof_steps = max(4, min(12, args.steps))
 
+    samples = {}
+
     def collect(e):
         e.sync()
         for tag, ms in e.kernel_times():
-            sym, _, layer = tag.partition(":")
-            a = agg.setdefault(sym, [0.0, 0])
-            a[0] += ms
-            a[1] += 1
-            if layer:
-                pl = per_layer.setdefault(tag, [0.0, 0])
-                pl[0] += ms
-                pl[1] += 1
+            samples.setdefault(tag, []).append(ms)
 
     pending = []
     for i in range(prof_steps):
@@ -229,6 +224,18 @@ def main():
         collect(e)
     for e in engines:
         e.set_profiling(False)
+    # a launch now and then lands on a stall that is not the kernel's (a 25 ms sample was seen once in a
+    # 0.04 ms kernel): samples beyond 4x the tag's median are left out of the averages
+    for tag, ms_list in samples.items():
+        med = float(np.median(ms_list))
+        kept = [m for m in ms_list if m <= 4.0 * med] or ms_list
+        mean = sum(kept) / len(kept)
+        sym, _, layer = tag.partition(":")
+        a = agg.setdefault(sym, [0.0, 0])
+        a[0] += mean * len(ms_list)
+        a[1] += len(ms_list)
+        if layer:
+            per_layer[tag] = [mean * len(ms_list), len(ms_list)]
     kernel_ms = {k: v[0] / prof_steps for k, v in agg.items()}        # per step
     launches = {k: v[1] / prof_steps for k, v in agg.items()}
     dominant = max(kernel_ms, key=kernel_ms.get)
