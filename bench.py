@@ -146,12 +146,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    comm_dev = f"cuda:{local_rank}"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # PP_BENCH_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
+        # (ranks share devices round-robin, the scalar all-reduces run on the CPU); the numbers mean nothing
+        backend = os.environ.get("PP_BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend)
+            comm_dev = "cpu"
         # communicator set-up (and RCCL's device buffers) now, before any engine memory or graph exists
-        warm = torch.ones(1, device=f"cuda:{local_rank}")
+        warm = torch.ones(1, device=comm_dev)
         dist.all_reduce(warm)
         dist.barrier()
         torch.cuda.synchronize()
@@ -191,8 +201,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = pp.frame_shard.max_over_ranks(elapsed, dist, f"cuda:{local_rank}")
-    counts = pp.frame_shard.gather_counts(B * args.steps, dist, f"cuda:{local_rank}")
+    elapsed = pp.frame_shard.max_over_ranks(elapsed, dist, comm_dev)
+    counts = pp.frame_shard.gather_counts(B * args.steps, dist, comm_dev)
     ms_per_step = elapsed / args.steps * 1e3
     fps = sum(counts) / elapsed
     dets, n_det = eng.detections()
@@ -242,7 +252,7 @@ def main():
     heads_fused = not any(t.endswith(":heads") for t in eng.layer_tags())
     lf = layer_flops(d, B, heads_fused)
     sb = stage_bytes(d, B, N, float(im_np.mean()))
-    if dominant.startswith(("k_gemm", "k_sep_u", "k_deconv_u")):
+    if dominant.startswith(("k_gemm", "k_sep_u", "k_deconv_u", "k_sep_k4", "k_deconv_k4")):
         # a GEMM layer has two roofs: the matrix pipe (float32 MFMA, or the bf16 pipe at 6 bf16 products per
         # float32 product for the split-precision kernels) and HBM (input read + output written once); the
         # one that allows less is the bound that is reported
@@ -251,7 +261,8 @@ def main():
         flops_launch = sum(lf[n] for n in mine) / launches[dominant]
         bytes_launch = sum(lb[n] for n in mine) / launches[dominant]
         avg_ms = kernel_ms[dominant] / launches[dominant]
-        split = dominant.startswith("k_deconv_u") or (dominant.startswith("k_sep_u") and dominant.endswith(",1>"))
+        split = (dominant.startswith(("k_deconv_u", "k_deconv_k4", "k_sep_k4")) or
+                 (dominant.startswith("k_sep_u") and dominant.endswith(",1>")))
         mfma_peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_TERMS if split else F32_MFMA_PEAK_TFLOPS
         tf = flops_launch / (avg_ms * 1e-3) / 1e12
         gbs = bytes_launch / (avg_ms * 1e-3) / 1e9
@@ -322,7 +333,8 @@ def main():
     for layer, (tms, cnt, sym) in iso_layer.items():
         t = tms / cnt * 1e-3
         if layer in lf:
-            split = sym.startswith("k_deconv_u") or (sym.startswith("k_sep_u") and sym.endswith(",1>"))
+            split = (sym.startswith(("k_deconv_u", "k_deconv_k4", "k_sep_k4")) or
+                     (sym.startswith("k_sep_u") and sym.endswith(",1>")))
             peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_TERMS if split else F32_MFMA_PEAK_TFLOPS
             roofs[layer] = {"kernel": sym, "ms": round(t * 1e3, 4), "GBps": round(lbytes[layer] / t / 1e9, 1),
                             "frac_hbm": round(lbytes[layer] / t / 1e9 / HBM_PEAK_GBS, 3),

@@ -454,3 +454,28 @@ def test_graph_cache_across_changing_batches(pp, engines):
             kk = int(n[b])
             assert np.array_equal(dets[b]["anchor_index"][:kk], dets2[b]["anchor_index"][:kk])
             assert np.array_equal(dets[b]["box3d_lidar"][:kk], dets2[b]["box3d_lidar"][:kk])
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_path_rehearsal(hip_lib):
+    """bench.py's N > 1 code path (rank env, frame shards, max-over-ranks timing, one JSON line on rank 0)
+    with two ranks sharing this box's GPU and `gloo` carrying the scalar all-reduces: the throughput it
+    prints means nothing, the contract fields do."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update({"PP_BENCH_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--batch", "8", "--no-latency-b1"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
+    assert d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
