@@ -15,7 +15,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_PKG), "include", "pp_hip.h")
 SO_PATH = os.path.join(_PKG, "libpp_hip.so")
 SOURCES = ["pp_api.hip", "voxelize.hip", "pfn.hip", "anchor_mask.hip", "backbone.hip", "postprocess.hip",
-           "rotate_iou.hip"]
+           "rotate_iou.hip", "loss.hip"]
 # -fno-slp-vectorize: keeps f32 FMAs as v_fma_f32; the SLP vectoriser's v_pk_fma_f32 is slow on a SIMD
 # that is also issuing MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
@@ -27,7 +27,7 @@ EXPORTS = [
     "pp_upload_points", "pp_upload_points_device", "pp_set_calib", "pp_detect_async", "pp_sync",
     "pp_get_detections", "pp_detect", "pp_fetch_intermediates", "pp_set_profiling", "pp_get_kernel_times",
     "pp_timer_start", "pp_timer_stop", "pp_device_info", "pp_bench_layer", "pp_layer_count", "pp_layer_tag",
-    "pp_rotate_iou_eval", "pp_d3_box_overlap",
+    "pp_rotate_iou_eval", "pp_d3_box_overlap", "pp_head_loss",
 ]
 
 
@@ -53,6 +53,23 @@ class PPConfig(ctypes.Structure):
         ("anchor_area_threshold", ctypes.c_float),
         ("max_batch", ctypes.c_int32),
         ("max_points_per_frame", ctypes.c_int32),
+    ]
+
+
+class PPLossConfig(ctypes.Structure):
+    _fields_ = [
+        ("alpha", ctypes.c_float),
+        ("gamma", ctypes.c_float),
+        ("sigma", ctypes.c_float),
+        ("code_weight", ctypes.c_float * 7),
+        ("pos_class_weight", ctypes.c_float),
+        ("neg_class_weight", ctypes.c_float),
+        ("classification_weight", ctypes.c_float),
+        ("localization_weight", ctypes.c_float),
+        ("direction_loss_weight", ctypes.c_float),
+        ("norm_by_num_positives", ctypes.c_int32),
+        ("encode_rad_error_by_sin", ctypes.c_int32),
+        ("use_direction_classifier", ctypes.c_int32),
     ]
 
 
@@ -140,6 +157,7 @@ def lib():
     L.pp_layer_tag.restype = ctypes.c_char_p
     L.pp_rotate_iou_eval.argtypes = [ctypes.c_int, f32p, i64, f32p, i64, i32, f32p]
     L.pp_d3_box_overlap.argtypes = [ctypes.c_int, vp, i64, vp, i64, i32, vp]
+    L.pp_head_loss.argtypes = [vp, vp, f32p, i32, ctypes.POINTER(PPLossConfig), f32p, f32p]
     for name in EXPORTS:
         fn = getattr(L, name)  # raises AttributeError if the symbol is not exported
         if name not in ("pp_last_error", "pp_layer_tag"):

@@ -41,6 +41,18 @@ _PEDESTRIAN_D435I = {
             "use_groupnorm": False,
             "num_groups": 32,
         },
+        # training-side keys (configs/train.yaml:147-167, :143), read by Engine.head_loss only
+        "encode_rad_error_by_sin": True,
+        "loss": {
+            "classification_loss": {"weighted_sigmoid_focal": {"alpha": 0.25, "gamma": 2.0, "anchorwise_output": True}},
+            "localization_loss": {"weighted_smooth_l1": {"sigma": 3.0, "code_weight": [1.0] * 7}},
+            "classification_weight": 1.0,
+            "localization_weight": 1.5,
+        },
+        "pos_class_weight": 1.0,
+        "neg_class_weight": 1.0,
+        "loss_norm_type": "NormByNumPositives",
+        "direction_loss_weight": 0.5,
         "use_sigmoid_score": True,
         "encode_background_as_zeros": True,
         "use_direction_classifier": True,

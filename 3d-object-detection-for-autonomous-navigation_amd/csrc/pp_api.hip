@@ -54,6 +54,12 @@ struct pp_engine {
     float* d_concat = nullptr;
     float* d_head = nullptr;      // fused head map [B][H'*W'][PP_HEAD_COLS]
     bool fuse_heads = false;      // heads computed in the deconv epilogues (no concat buffer, no head launch)
+    int* d_loss_labels = nullptr;      // training-side buffers (pp_head_loss), allocated on first use
+    float* d_loss_regt = nullptr;
+    int* d_loss_npos = nullptr;
+    double* d_loss_partials = nullptr;
+    float* d_loss_out = nullptr;
+    float* d_head_grad = nullptr;
     int* d_integ = nullptr;
     uint8_t* d_mask = nullptr;
     float* d_anchors = nullptr;
@@ -1176,6 +1182,51 @@ int pp_d3_box_overlap(int device, const double* boxes, int64_t n, const double* 
     RCHK(hipGetLastError());
     RCHK(hipMemcpy(out, d_o.p, sizeof(double) * n * k, hipMemcpyDeviceToHost));
 #undef RCHK
+    return PP_OK;
+}
+
+int pp_head_loss(pp_handle e, const int32_t* labels, const float* reg_targets, int32_t batch,
+                 const pp_loss_config* lc, float* losses, float* head_grad) {
+    if (!e) return PP_ERR_ARG;
+    if (!labels || !reg_targets || !lc || !losses) return fail(e, PP_ERR_ARG, "pp_head_loss: null argument");
+    if (!e->anchors_ready) return fail(e, PP_ERR_STATE, "pp_head_loss: anchors not set");
+    int st = check_batch(e, batch);
+    if (st) return st;
+    if (!(lc->sigma > 0.f)) return fail(e, PP_ERR_ARG, "pp_head_loss: sigma must be positive");
+    if (e->cfg.num_class != 1) return fail(e, PP_ERR_UNSUPPORTED, "pp_head_loss: one class only (like the reference's predict)");
+    (void)hipSetDevice(e->device);
+    const size_t npx = (size_t)e->head_h * e->head_w;
+    if (!e->d_head_grad) {   // training-side buffers: allocated on first use
+        if ((st = dalloc(e, &e->d_loss_labels, (size_t)e->B * e->A))) return st;
+        if ((st = dalloc(e, &e->d_loss_regt, (size_t)e->B * e->A * 7))) return st;
+        if ((st = dalloc(e, &e->d_loss_npos, (size_t)e->B))) return st;
+        if ((st = dalloc(e, &e->d_loss_partials, (size_t)e->B * loss_blocks((int)npx) * 5))) return st;
+        if ((st = dalloc(e, &e->d_loss_out, (size_t)8))) return st;
+        if ((st = dalloc(e, &e->d_head_grad, (size_t)e->B * npx * PP_HEAD_COLS))) return st;
+    }
+    HIPCHK(e, hipMemcpyAsync(e->d_loss_labels, labels, (size_t)batch * e->A * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_loss_regt, reg_targets, (size_t)batch * e->A * 7 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    LossParams p;
+    memset(&p, 0, sizeof(p));
+    p.batch = batch; p.A = e->A; p.npx = (int)npx; p.napl = e->napl;
+    p.head = e->d_head; p.labels = e->d_loss_labels; p.reg_targets = e->d_loss_regt; p.anchors = e->d_anchors;
+    p.npos = e->d_loss_npos; p.partials = e->d_loss_partials; p.losses = e->d_loss_out;
+    p.head_grad = head_grad ? e->d_head_grad : nullptr;
+    p.alpha = lc->alpha; p.gamma = lc->gamma; p.sigma = lc->sigma;
+    for (int i = 0; i < 7; ++i) p.code_weight[i] = lc->code_weight[i];
+    p.pos_cls_weight = lc->pos_class_weight; p.neg_cls_weight = lc->neg_class_weight;
+    p.cls_weight = lc->classification_weight; p.loc_weight = lc->localization_weight; p.dir_weight = lc->direction_loss_weight;
+    p.norm_by_num_positives = lc->norm_by_num_positives; p.encode_rad_error_by_sin = lc->encode_rad_error_by_sin;
+    p.use_direction = lc->use_direction_classifier;
+    {
+        ProfScope ps(e, "k_loss_pixels:loss+grad");
+        if ((st = launch_head_loss(p, e->stream))) return fail(e, st, "pp_head_loss: %d anchors per pixel not supported", e->napl);
+    }
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemcpyAsync(losses, e->d_loss_out, 8 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (head_grad)
+        HIPCHK(e, hipMemcpyAsync(head_grad, e->d_head_grad, (size_t)batch * npx * PP_HEAD_COLS * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
     return PP_OK;
 }
 

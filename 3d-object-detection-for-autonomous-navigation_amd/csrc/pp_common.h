@@ -113,6 +113,28 @@ struct PostParams {
 };
 void launch_postprocess(const PostParams& p, hipStream_t s);
 
+// loss.hip: training loss at the head maps + gradient with respect to them
+struct LossParams {
+    int batch;
+    int64_t A;             // anchors per frame
+    int npx, napl;         // head pixels per frame, anchors per pixel
+    const float* head;     // [batch][npx][PP_HEAD_COLS]
+    const int* labels;     // [batch][A]  (>0 class, 0 background, -1 ignored)
+    const float* reg_targets;  // [batch][A][7]
+    const float* anchors;  // [A][7]
+    int* npos;             // [batch] scratch: positives per frame
+    double* partials;      // [batch * blocks][5] scratch
+    float* losses;         // [8] out
+    float* head_grad;      // [batch][npx][PP_HEAD_COLS] out, may be NULL
+    float alpha, gamma, sigma;
+    float code_weight[7];
+    float pos_cls_weight, neg_cls_weight;
+    float cls_weight, loc_weight, dir_weight;
+    int norm_by_num_positives, encode_rad_error_by_sin, use_direction;
+};
+int loss_blocks(int npx);
+int launch_head_loss(const LossParams& p, hipStream_t s);   // 0 or PP_ERR_UNSUPPORTED (anchors per pixel > 3)
+
 // rotate_iou.hip: rotated-box overlaps of the AP evaluator
 void launch_riou_corners(const float* boxes, int64_t n, float* corners, hipStream_t s);
 void launch_riou_pairs(const float* bc, int64_t N, const float* qc, int64_t K, int criterion, float* out, hipStream_t s);

@@ -255,6 +255,56 @@ class Engine:
                     "pp_bench_layer")
         return float(t.value)
 
+    def loss_config(self):
+        """The reference's loss keys (model.second.loss..., configs/train.yaml:147-167) as the C-ABI struct."""
+        s = self.d.config["model"]["second"]
+        lc = _lib.PPLossConfig()
+        focal = s["loss"]["classification_loss"]["weighted_sigmoid_focal"]
+        l1 = s["loss"]["localization_loss"]["weighted_smooth_l1"]
+        lc.alpha = -1.0 if focal["alpha"] is None else float(focal["alpha"])
+        lc.gamma = float(focal["gamma"] or 0.0)
+        lc.sigma = float(l1["sigma"])
+        for i, v in enumerate(l1["code_weight"]):
+            lc.code_weight[i] = float(v)
+        lc.pos_class_weight = float(s["pos_class_weight"])
+        lc.neg_class_weight = float(s["neg_class_weight"])
+        lc.classification_weight = float(s["loss"]["classification_weight"])
+        lc.localization_weight = float(s["loss"]["localization_weight"])
+        lc.direction_loss_weight = float(s["direction_loss_weight"])
+        lc.norm_by_num_positives = 1 if s["loss_norm_type"] == "NormByNumPositives" else 0
+        lc.encode_rad_error_by_sin = 1 if s["encode_rad_error_by_sin"] else 0
+        lc.use_direction_classifier = 1 if s["use_direction_classifier"] else 0
+        return lc
+
+    def head_loss(self, labels, reg_targets, want_grad=True):
+        """Training loss of the head maps the last forward pass left on the device (VoxelNet.call in training
+        mode, model/voxelnet.py:922-1049) and its gradient with respect to them.  labels [B, A] int32,
+        reg_targets [B, A, 7] float32 (the dataloader's `labels` / `reg_targets`).  Returns the reference's
+        scalar keys and, if asked, `box_preds_grad` / `cls_preds_grad` / `dir_cls_preds_grad` shaped like
+        the head maps."""
+        labels = _i32(np.asarray(labels))
+        batch = labels.shape[0]
+        reg_targets = _f32(np.asarray(reg_targets).reshape(batch, self.d.num_anchors, 7))
+        if labels.shape != (batch, self.d.num_anchors):
+            raise ValueError(f"labels must be [B, {self.d.num_anchors}]")
+        losses = np.zeros(8, np.float32)
+        hh, hw = self.d.head_h, self.d.head_w
+        grad = np.zeros((batch, hh * hw, 32), np.float32) if want_grad else None
+        lc = self.loss_config()
+        self._check(self._lib.pp_head_loss(self._h, _ptr(labels), _ptr(reg_targets), batch, ctypes.byref(lc),
+                                           _ptr(losses), _ptr(grad) if want_grad else None), "pp_head_loss")
+        out = {"loss": float(losses[0]), "loc_loss_reduced": float(losses[1]), "cls_loss_reduced": float(losses[2]),
+               "dir_loss_reduced": float(losses[3]), "cls_pos_loss": float(losses[4]), "cls_neg_loss": float(losses[5]),
+               "num_positives": int(losses[6])}
+        if want_grad:
+            na = self.d.num_anchor_per_loc
+            nb = na * 7
+            out["head_grad"] = grad
+            out["box_preds_grad"] = grad[:, :, :nb].reshape(batch, hh, hw, nb)
+            out["cls_preds_grad"] = grad[:, :, nb:nb + na].reshape(batch, hh, hw, na)
+            out["dir_cls_preds_grad"] = grad[:, :, nb + na:nb + 3 * na].reshape(batch, hh, hw, 2 * na)
+        return out
+
     def timer_start(self):
         self._check(self._lib.pp_timer_start(self._h), "pp_timer_start")
 

@@ -207,6 +207,34 @@ int pp_rotate_iou_eval(int device, const float* boxes, int64_t n, const float* q
 int pp_d3_box_overlap(int device, const double* boxes, int64_t n, const double* query_boxes, int64_t k,
                       int32_t criterion, double* out);
 
+/* ---- training loss at the head maps ---------- */
+
+/* Mirrors model.second.loss / pos_class_weight / ... of configs/train.yaml:147-167. */
+typedef struct pp_loss_config {
+    float alpha;             /* weighted_sigmoid_focal.alpha (0.25); negative = no alpha weighting */
+    float gamma;             /* weighted_sigmoid_focal.gamma (2.0) */
+    float sigma;             /* weighted_smooth_l1.sigma (3.0) */
+    float code_weight[7];    /* weighted_smooth_l1.code_weight */
+    float pos_class_weight, neg_class_weight;
+    float classification_weight, localization_weight, direction_loss_weight;
+    int32_t norm_by_num_positives;     /* loss_norm_type == "NormByNumPositives" */
+    int32_t encode_rad_error_by_sin;   /* model.second.encode_rad_error_by_sin */
+    int32_t use_direction_classifier;
+} pp_loss_config;
+
+/* Replaces the loss half of VoxelNet.call in training mode (model/voxelnet.py:922-1049: prepare_loss_weights
+ * :461-512, create_loss :74-155, sigmoid_focal_classification_loss :262-364, WeightedSmoothL1LocalizationLoss
+ * :407-459, get_direction_target :38-46, weighted_softmax_classification_loss :180-235) on the head maps the
+ * last forward pass of this handle left on the device (pp_detect / pp_detect_async + pp_sync /
+ * pp_forward_voxels with the same `batch`).  labels [batch][A] int32 (>0 class, 0 background, -1 ignored),
+ * reg_targets [batch][A][7] float32: the dataloader's `labels` / `reg_targets` (load_data.py:3096-3100).
+ * losses[8] = {loss, loc_loss_reduced, cls_loss_reduced, dir_loss_reduced, cls_pos_loss, cls_neg_loss,
+ * number of positive anchors, 0}.  head_grad (may be NULL): d loss / d head map, [batch][H'*W'][32] float32 in
+ * the fused head-map layout [box napl*7 | cls napl | dir napl*2 | zero pad] -- what the backward pass of the
+ * head GEMM consumes.  Host pointers; synchronous. */
+int pp_head_loss(pp_handle h, const int32_t* labels, const float* reg_targets, int32_t batch,
+                 const pp_loss_config* cfg, float* losses, float* head_grad);
+
 /* Device properties for reports: name (<=255 chars), CU count, bytes of HBM. */
 int pp_device_info(pp_handle h, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes);
 

@@ -18,6 +18,9 @@ Pinning status (see DESIGN.md "Oracle"):
   * the predict path's `+1` IoU (`iou_device`): formula PINNED to 1e-6 against the same kind of
     run (ref_iou_device.npz); the last bits follow numba's float32+int64 -> float64 typing rule,
     which a plain-Python run does not reproduce.
+  * training loss at the head maps (`loss_ref.py`, torch-CPU restatement of model/voxelnet.py:922-1049):
+    PARITY UNPINNED (TensorFlow graph in the reference); cross-checked against float64 numpy formulas and
+    finite differences.
   * PFN / scatter / RPN (TensorFlow Keras layers), the numba-CUDA `nms_kernel` indexing
     and `VoxelNet.predict` glue: PARITY UNPINNED -- TensorFlow 2.2 and numba
     0.51 are not installable here and the reference ships no tests or golden
