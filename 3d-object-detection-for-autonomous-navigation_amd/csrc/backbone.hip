@@ -85,6 +85,8 @@ struct GemmArgs {
     int ld_out, co_off;
     int epi;              // 0: bias+ReLU rows; 1: deconv pixel-shuffle; 2: heads
     int k, cout;          // deconv
+    const int* occ;       // sparse input (k_sep_u<..., OCC = 1> / k_sep_k4): cell -> pillar map, see LayerDesc::d_occ
+    int occ_nz;
 };
 
 // D[row][col] of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -713,7 +715,9 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float inv_d, int& q, i
 // stores straight from the accumulators: for a fixed accumulator register the 32 lanes of a
 // half-wave hold 32 consecutive channels of one pixel = one full 128-byte line.
 // PREC 0: float32 MFMA (v_mfma_f32_32x32x2_f32); PREC 1: split-precision bf16 MFMA (see split_bf16x3).
-template <int NT, int S, int WPS, int PREC>
+// OCC 1: the input is the sparse canvas (only cells that hold a pillar were written): every window position
+// looks its cell up in the cell -> pillar map at tile start and reads the zero header when it is empty.
+template <int NT, int S, int WPS, int PREC, int OCC = 0>
 __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     constexpr int KCH = 16, LSTR = KCH + 4, G = 4;
     constexpr int WW = S + 3;                        // input window width of 2 adjacent output pixels
@@ -794,8 +798,15 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
             (unsigned)(((b_ * a.in_h + y_ * S) * a.in_w + x0_ * S) * cin) * 4u + PP_ZPAD_FLOATS * 4u;    \
         _Pragma("unroll") for (int e = 0; e < NLD; ++e) {                                                \
             const int dy_ = e / WW, dx_ = e % WW;                                                        \
-            const bool ok_ = pvalid_ && yi_ + dy_ >= 0 && yi_ + dy_ < a.in_h && xi_ + dx_ >= 0 &&        \
-                             xi_ + dx_ < a.in_w && !(dbg & 8);                                           \
+            bool ok_ = pvalid_ && yi_ + dy_ >= 0 && yi_ + dy_ < a.in_h && xi_ + dx_ >= 0 &&              \
+                       xi_ + dx_ < a.in_w && !(dbg & 8);                                                 \
+            if (OCC) {                                                                                   \
+                bool occ_ = false;                                                                       \
+                const int cidx_ = ok_ ? (yi_ + dy_) * a.in_w + xi_ + dx_ : 0;                            \
+                for (int z_ = 0; z_ < a.occ_nz; ++z_)                                                    \
+                    occ_ = occ_ || a.occ[(size_t)(b_ * a.occ_nz + z_) * (a.in_h * a.in_w) + cidx_] >= 0; \
+                ok_ = ok_ && occ_;                                                                       \
+            }                                                                                            \
             aoff[e] = (ok_ ? cbase_ + (unsigned)((dy_ - 1) * rs4 + (dx_ - 1) * cin4) : 0u) +             \
                       (unsigned)(c4 * 16);                                                               \
         }                                                                                                \
@@ -1030,7 +1041,9 @@ static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
     int gx = ntiles < slots ? ntiles : slots;
     gx = (gx + 7) & ~7;
     dim3 grid((unsigned)gx, ny);
-    if (bf)
+    if (bf && a.occ != nullptr)
+        hipLaunchKernelGGL((k_sep_u<NT, S, WPB, 1, 1>), grid, dim3(256), 0, s, a, ntiles);
+    else if (bf)
         hipLaunchKernelGGL((k_sep_u<NT, S, WPB, 1>), grid, dim3(256), 0, s, a, ntiles);
     else
         hipLaunchKernelGGL((k_sep_u<NT, S, WPS, 0>), grid, dim3(256), 0, s, a, ntiles);
@@ -1089,7 +1102,14 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
 #pragma unroll
         for (int e = 0; e < NLD; ++e) {
             const int dy = e / WW, dx = e % WW;
-            const bool ok = pvalid && yi + dy >= 0 && yi + dy < a.in_h && xi + dx >= 0 && xi + dx < a.in_w;
+            bool ok = pvalid && yi + dy >= 0 && yi + dy < a.in_h && xi + dx >= 0 && xi + dx < a.in_w;
+            if (a.occ != nullptr) {   // sparse canvas: empty cells were not written
+                bool occ = false;
+                const int cidx = ok ? (yi + dy) * a.in_w + xi + dx : 0;
+                for (int z = 0; z < a.occ_nz; ++z)
+                    occ = occ || a.occ[(size_t)(b * a.occ_nz + z) * (a.in_h * a.in_w) + cidx] >= 0;
+                ok = ok && occ;
+            }
             aoff[e] = (ok ? cbase + (unsigned)((dy - 1) * rs4 + (dx - 1) * cin4) : 0u) + (unsigned)(c4 * 16);
         }
     }
@@ -1790,6 +1810,12 @@ static bool deconv_uniform(const LayerDesc& L, int ablate) {
     return true;
 }
 
+// can layer L (a separable layer) read a sparse canvas at this batch size?  (the kernels with the cell-map lookup)
+bool sparse_input_supported(const LayerDesc& L, int batch) {
+    return L.kind == LAYER_SEP && use_ws(L) && sep_uniform(0) && L.d_wt16 != nullptr && split_precision(0) &&
+           (long long)batch * L.out_h * L.out_w < (1 << 24);
+}
+
 // a deconv can carry the fused head GEMM when one workgroup column covers the tap's whole channel
 // range (NT == cout) and the wave-specialised kernel runs it
 bool deconv_can_fuse_heads(const LayerDesc& L) {
@@ -1847,10 +1873,14 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
     a.in_h = L.in_h; a.in_w = L.in_w; a.cin = L.cin;
     a.stride = L.stride; a.ld_out = L.ld_out; a.co_off = L.co_off;
     a.k = L.k; a.cout = L.cout;
+    a.occ = L.d_occ; a.occ_nz = L.occ_nz;
     if (L.kind == LAYER_SEP) {
         a.px_h = L.out_h; a.px_w = L.out_w; a.epi = 0;
         a.M = batch * L.out_h * L.out_w;
         if (L.cout % 32 != 0) return PP_ERR_UNSUPPORTED;
+        // a sparse input is only understood by the split-precision uniform-wave / split-K kernels
+        if (a.occ != nullptr && !(sparse_input_supported(L, batch) && split_precision(ablate) && sep_uniform(ablate)))
+            return PP_ERR_UNSUPPORTED;
         if (use_ws(L) && sep_uniform(ablate) && a.M < (1 << 24)) {   // k_sep_u's float-reciprocal index math
             const int nt = sep_u_nt(L, batch);
             if (!(ablate & 16) && sep_k4_runs(a.wt16, a.cin, L.n_total, a.M, ablate)) {   // small map

@@ -251,6 +251,11 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
         const int c = lane / nz, z = lane - c * nz;
         slot_cell = c;
         pid = p.cellmap[((size_t)b * nz + z) * ncanvas + cell0 + c];
+    }
+    // sparse canvas: most waves of a mostly empty grid have nothing to write -- leave before any other work
+    if (p.sparse && __ballot(pid >= 0) == 0ull) return;
+    if (lane < NS) {
+        const int c = slot_cell;
         if (pid >= 0) {
             start = ps[pid];
             cnt = min(ps[pid + 1] - start, T);
@@ -285,6 +290,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     }
     const int excl = incl - cnt;
     const int tot = __builtin_amdgcn_readlane(incl, 63);
+    if (p.sparse && tot == 0) return;                 // sparse canvas: nothing to write for cells without pillars
     const unsigned* sidx = p.sorted_idx + n0;
     const float* src = p.pts + (size_t)n0 * F;
 
@@ -317,8 +323,11 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     for (int q = 0; q < CPL; ++q) { acc[q] = 0.f; m[q] = -3.0e38f; }
     int cur_slot = -1, cur_cell = 0;
     float cxf = 0.f, cyf = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;      // wave-uniform values (same in every lane)
+    bool cell_dirty = false;                          // a pillar of the current cell has been added (wave-uniform)
     auto write_cell = [&](int c) {
-        if (ch_ok) {
+        // sparse canvas: cells without a pillar are not written at all (the first layer looks the cell up in
+        // the cell map and reads zeros); writing the zeros of an almost empty grid is most of the traffic
+        if (ch_ok && (cell_dirty || !p.sparse)) {
             float* dst = cbase + (size_t)c * C + ch0;
             if constexpr (CPL == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             else if constexpr (CPL == 2) *reinterpret_cast<float2*>(dst) = make_float2(acc[0], acc[1]);
@@ -326,6 +335,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
         }
 #pragma unroll
         for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
+        cell_dirty = false;
     };
     auto finish_slot = [&](int s) {
         const int n = __builtin_amdgcn_readlane(cnt, s);
@@ -354,6 +364,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
         }
 #pragma unroll
         for (int q = 0; q < CPL; ++q) { acc[q] += m[q]; m[q] = -3.0e38f; }
+        cell_dirty = true;
     };
     auto begin_slot = [&](int s) {
         const int c = __builtin_amdgcn_readlane(slot_cell, s);

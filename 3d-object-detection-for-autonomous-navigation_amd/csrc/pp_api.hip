@@ -54,6 +54,7 @@ struct pp_engine {
     float* d_concat = nullptr;
     float* d_head = nullptr;      // fused head map [B][H'*W'][PP_HEAD_COLS]
     bool fuse_heads = false;      // heads computed in the deconv epilogues (no concat buffer, no head launch)
+    bool sparse_canvas = false;   // PFN writes occupied cells only; layer 0 consults the cell map (pp_finalize_weights)
     int* d_loss_labels = nullptr;      // training-side buffers (pp_head_loss), allocated on first use
     float* d_loss_regt = nullptr;
     int* d_loss_npos = nullptr;
@@ -249,6 +250,24 @@ std::vector<float> split_weights_bf16x3(const std::vector<float>& wt, int n_tota
     return packed;
 }
 
+// canvas -> host (debug taps).  With the sparse canvas the cells without a pillar were never written: they are
+// zeroed here from the cell map, so the caller sees the dense pseudo-image of the reference.
+static int fetch_canvas(pp_engine* e, float* canvas, int batch) {
+    const size_t plane = (size_t)e->ny * e->nx;
+    HIPCHK(e, hipMemcpyAsync(canvas, e->d_canvas, (size_t)batch * plane * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (!e->sparse_canvas) return PP_OK;
+    std::vector<int> cm((size_t)batch * e->nz * plane);
+    HIPCHK(e, hipMemcpy(cm.data(), e->d_cellmap, cm.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < batch; ++b)
+        for (size_t c = 0; c < plane; ++c) {
+            bool occ = false;
+            for (int z = 0; z < e->nz; ++z) occ = occ || cm[((size_t)b * e->nz + z) * plane + c] >= 0;
+            if (!occ) memset(canvas + ((size_t)b * plane + c) * e->C, 0, (size_t)e->C * sizeof(float));
+        }
+    return PP_OK;
+}
+
 // ---- stage pipelines (all enqueue on e->stream) ----
 int run_voxelize(pp_engine* e, int batch, int max_n) {
     const bool lds_first = voxel_first_in_lds(max_n, e->ncell, e->cfg.max_voxels);
@@ -290,6 +309,7 @@ int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out) {
     p.pts = e->d_points; p.offsets = e->d_offsets; p.sorted_idx = sorted_idx(e); p.pillar_start = e->d_pstart;
     p.voxels = e->d_voxels; p.num_points = e->d_numpts;
     p.canvas = e->d_canvas; p.feat_out = feat_out;
+    p.sparse = e->sparse_canvas ? 1 : 0;
     ProfScope ps(e, "k_pfn_canvas:pfn+scatter");
     int st = launch_pfn(p, padded, e->stream);
     if (st) return fail(e, st, "PFN: unsupported C=%d / F=%d", e->C, e->F);
@@ -700,6 +720,19 @@ int pp_finalize_weights(pp_handle e) {
             st = upload(e, &L.d_bias, headb); if (st) return st;
         }
     }
+    // sparse canvas: on a large, mostly empty BEV grid (KITTI-shaped: 214 k cells, <= 12 k pillars) writing and
+    // re-reading the zeros of the pseudo-image is most of the PFN's and the first layer's traffic.  The PFN then
+    // writes only the cells that hold a pillar and the first layer looks every window position up in the cell
+    // map.  Needs the kernels that know the lookup (sparse_input_supported); PP_DENSE_CANVAS=1 turns it off.
+    {
+        const char* env = getenv("PP_DENSE_CANVAS");
+        const long long cells = (long long)e->ny * e->nx;
+        LayerDesc& L0 = e->layers[0];
+        e->sparse_canvas = !(env && env[0] == '1') && cells >= 32768 && 4ll * e->cfg.max_voxels <= cells &&
+                           L0.in == e->d_canvas && sparse_input_supported(L0, e->B);
+        L0.d_occ = e->sparse_canvas ? e->d_cellmap : nullptr;
+        L0.occ_nz = e->nz;
+    }
     e->weights_ready = true;
     return PP_OK;
 }
@@ -951,9 +984,8 @@ int pp_forward_voxels(pp_handle e, const float* voxels, const int32_t* num_point
     if ((st = fetch_heads(e, batch, box_preds, cls_preds, dir_cls_preds))) return st;
     if (pillar_features && P)
         HIPCHK(e, hipMemcpyAsync(pillar_features, e->d_feat, (size_t)P * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    if (canvas)
-        HIPCHK(e, hipMemcpyAsync(canvas, e->d_canvas, (size_t)batch * e->ny * e->nx * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (canvas && (st = fetch_canvas(e, canvas, batch))) return st;
     return PP_OK;
 }
 
@@ -1013,7 +1045,7 @@ int pp_fetch_intermediates(pp_handle e, int32_t* n_pillars, int32_t* coors, int3
         int st = fetch_heads(e, B, box_preds, cls_preds, dir_cls_preds);
         if (st) return st;
     }
-    if (canvas) HIPCHK(e, hipMemcpy(canvas, e->d_canvas, (size_t)B * e->ny * e->nx * e->C * sizeof(float), hipMemcpyDeviceToHost));
+    if (canvas) { int stc = fetch_canvas(e, canvas, B); if (stc) return stc; }
     return PP_OK;
 }
 

@@ -50,6 +50,10 @@ struct LayerDesc {
     float* d_head_wt;     // [PP_HEAD_COLS][cout] slice of the head kernels, transposed
     float* d_head_bias;   // [PP_HEAD_COLS]
     float* d_head_wt16;   // d_head_wt as three bf16 pieces, [cout/16][3][PP_HEAD_COLS][16] 16-bit words (or NULL)
+    // sparse canvas (first layer only): cell -> pillar map [batch][occ_nz][in_h][in_w]; a window position whose
+    // cell holds no pillar is read from the zero header instead of the (unwritten) canvas.  NULL: dense input
+    const int* d_occ;
+    int occ_nz;
     const char* name;
 };
 
@@ -86,6 +90,7 @@ struct PfnParams {
     const int* num_points;
     // outputs
     float* canvas;    // [batch][ny][nx][C]
+    int sparse;       // 1: only cells that hold a pillar are written (the first layer consults the cell map)
     float* feat_out;  // optional [P][C]
 };
 int launch_pfn(const PfnParams& p, bool padded_source, hipStream_t s);  // returns 0 or PP_ERR_UNSUPPORTED
@@ -94,6 +99,7 @@ void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, c
                         float threshold, int* integ, uint8_t* mask, hipStream_t s);
 
 bool deconv_can_fuse_heads(const LayerDesc& L);
+bool sparse_input_supported(const LayerDesc& L, int batch);   // may L's input be a canvas with unwritten empty cells?
 std::string layer_kernel_name(const LayerDesc& L, int batch);  // template instantiation that runs L at this batch
 int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s,
                  int ablate = 0);  // returns 0 or PP_ERR_UNSUPPORTED

@@ -352,7 +352,11 @@ def test_kitti_shaped_forward(pp, engines):
     rect, trv, p2 = pp.synth.default_calib()
     ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
     dets, n = eng.detect(frames, rect[None], trv[None])
-    im = eng.intermediates()
+    # (this grid runs the sparse canvas: the PFN writes occupied cells only, block1.0 consults the cell map,
+    # and the debug tap zero-fills the cells that were never written)
+    im = eng.intermediates(canvas=True)
+    np.testing.assert_allclose(im["canvas"], ref["canvas"], rtol=1e-5, atol=1e-5)
+    assert (np.abs(im["canvas"]).sum(axis=-1) == 0).mean() > 0.9, "mostly empty grid"
     fr = ref["frames"][0]
     P = fr["coordinates"].shape[0]
     assert im["n_pillars"][0] == P and np.array_equal(im["coors"][0, :P], fr["coordinates"])
@@ -383,7 +387,7 @@ def test_error_behaviour(pp, engines):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"PP_GEMM_PREC": "f32"}, {"PP_GEMM_PREC": "f32", "PP_SEP_KERNEL": "ws"},
                                  {"PP_PFN_KERNEL": "1"}, {"PP_NO_HEAD_FUSION": "1"},
-                                 {"PP_NO_GRAPH": "1", "PP_SEP_NT": "64"}, {"PP_SEP_K4": "0", "PP_DECONV_K4": "0"}])
+                                 {"PP_NO_GRAPH": "1", "PP_SEP_NT": "64"}, {"PP_SEP_K4": "0", "PP_DECONV_K4": "0"}, {"PP_DENSE_CANVAS": "1"}])
 def test_fallback_kernel_generations_stay_in_parity(hip_lib, env):
     """The earlier kernel generations are selectable at process start (fp32-MFMA instantiations, the
     producer/consumer GEMM, the first PFN); one child process per selection runs the whole path on two
