@@ -796,19 +796,29 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         const int yi_ = y_ * S - 1, xi_ = x0_ * S - 1;                                                   \
         const unsigned cbase_ =                                                                          \
             (unsigned)(((b_ * a.in_h + y_ * S) * a.in_w + x0_ * S) * cin) * 4u + PP_ZPAD_FLOATS * 4u;    \
+        /* row and column validity are separable; non-short-circuit '&' keeps this straight-line code   \
+           (the '&&' form compiled to a nest of exec-mask branches per window element) */                \
+        bool rowok_[3], colok_[WW];                                                                      \
+        unsigned rowoff_[3], coloff_[WW];                                                                \
+        _Pragma("unroll") for (int dy_ = 0; dy_ < 3; ++dy_) {                                            \
+            rowok_[dy_] = pvalid_ & ((unsigned)(yi_ + dy_) < (unsigned)a.in_h) & !(dbg & 8);             \
+            rowoff_[dy_] = cbase_ + (unsigned)((dy_ - 1) * rs4);                                         \
+        }                                                                                                \
+        _Pragma("unroll") for (int dx_ = 0; dx_ < WW; ++dx_) {                                           \
+            colok_[dx_] = (unsigned)(xi_ + dx_) < (unsigned)a.in_w;                                      \
+            coloff_[dx_] = (unsigned)((dx_ - 1) * cin4);                                                 \
+        }                                                                                                \
         _Pragma("unroll") for (int e = 0; e < NLD; ++e) {                                                \
             const int dy_ = e / WW, dx_ = e % WW;                                                        \
-            bool ok_ = pvalid_ && yi_ + dy_ >= 0 && yi_ + dy_ < a.in_h && xi_ + dx_ >= 0 &&              \
-                       xi_ + dx_ < a.in_w && !(dbg & 8);                                                 \
+            bool ok_ = rowok_[dy_] & colok_[dx_];                                                        \
             if (OCC) {                                                                                   \
                 bool occ_ = false;                                                                       \
                 const int cidx_ = ok_ ? (yi_ + dy_) * a.in_w + xi_ + dx_ : 0;                            \
                 for (int z_ = 0; z_ < a.occ_nz; ++z_)                                                    \
-                    occ_ = occ_ || a.occ[(size_t)(b_ * a.occ_nz + z_) * (a.in_h * a.in_w) + cidx_] >= 0; \
-                ok_ = ok_ && occ_;                                                                       \
+                    occ_ = occ_ | (a.occ[(size_t)(b_ * a.occ_nz + z_) * (a.in_h * a.in_w) + cidx_] >= 0); \
+                ok_ = ok_ & occ_;                                                                        \
             }                                                                                            \
-            aoff[e] = (ok_ ? cbase_ + (unsigned)((dy_ - 1) * rs4 + (dx_ - 1) * cin4) : 0u) +             \
-                      (unsigned)(c4 * 16);                                                               \
+            aoff[e] = (ok_ ? rowoff_[dy_] + coloff_[dx_] : 0u) + (unsigned)(c4 * 16);                    \
         }                                                                                                \
     }
     // weight staging items (16 bytes each): global byte offset and LDS float offset, fixed for the K loop
@@ -1102,13 +1112,13 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
 #pragma unroll
         for (int e = 0; e < NLD; ++e) {
             const int dy = e / WW, dx = e % WW;
-            bool ok = pvalid && yi + dy >= 0 && yi + dy < a.in_h && xi + dx >= 0 && xi + dx < a.in_w;
+            bool ok = pvalid & ((unsigned)(yi + dy) < (unsigned)a.in_h) & ((unsigned)(xi + dx) < (unsigned)a.in_w);
             if (a.occ != nullptr) {   // sparse canvas: empty cells were not written
                 bool occ = false;
                 const int cidx = ok ? (yi + dy) * a.in_w + xi + dx : 0;
                 for (int z = 0; z < a.occ_nz; ++z)
-                    occ = occ || a.occ[(size_t)(b * a.occ_nz + z) * (a.in_h * a.in_w) + cidx] >= 0;
-                ok = ok && occ;
+                    occ = occ | (a.occ[(size_t)(b * a.occ_nz + z) * (a.in_h * a.in_w) + cidx] >= 0);
+                ok = ok & occ;
             }
             aoff[e] = (ok ? cbase + (unsigned)((dy - 1) * rs4 + (dx - 1) * cin4) : 0u) + (unsigned)(c4 * 16);
         }
