@@ -365,6 +365,13 @@ def test_kitti_shaped_forward(pp, engines):
         np.testing.assert_allclose(im[k], ref["preds"][k], rtol=TOL, atol=TOL)
     got = [pp.VoxelNet._to_dict(dets[0], int(n[0]), 0)]
     _assert_dets(got, ref["dets"])
+    # the compat entry (padded voxels in, head maps out) on the same sparse-canvas engine: its PFN writes the
+    # whole pseudo-image, block1.0 still goes through the cell map built from the given coordinates
+    ex = ref["example"]
+    out = eng.forward_voxels(ex[0], ex[1], ex[2], B, want_canvas=True)
+    np.testing.assert_allclose(out["canvas"], ref["canvas"], rtol=1e-5, atol=1e-5)
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        np.testing.assert_allclose(out[k], ref["preds"][k], rtol=TOL, atol=TOL)
 
 
 def test_error_behaviour(pp, engines):
