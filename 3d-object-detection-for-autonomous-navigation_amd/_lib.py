@@ -15,7 +15,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_PKG), "include", "pp_hip.h")
 SO_PATH = os.path.join(_PKG, "libpp_hip.so")
 SOURCES = ["pp_api.hip", "voxelize.hip", "pfn.hip", "anchor_mask.hip", "backbone.hip", "postprocess.hip",
-           "rotate_iou.hip", "loss.hip"]
+           "rotate_iou.hip", "loss.hip", "optim.hip"]
 # -fno-slp-vectorize: keeps f32 FMAs as v_fma_f32; the SLP vectoriser's v_pk_fma_f32 is slow on a SIMD
 # that is also issuing MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
@@ -27,7 +27,7 @@ EXPORTS = [
     "pp_upload_points", "pp_upload_points_device", "pp_set_calib", "pp_detect_async", "pp_sync",
     "pp_get_detections", "pp_detect", "pp_fetch_intermediates", "pp_set_profiling", "pp_get_kernel_times",
     "pp_timer_start", "pp_timer_stop", "pp_device_info", "pp_bench_layer", "pp_layer_count", "pp_layer_tag",
-    "pp_rotate_iou_eval", "pp_d3_box_overlap", "pp_head_loss",
+    "pp_rotate_iou_eval", "pp_d3_box_overlap", "pp_head_loss", "pp_adamw_step_device",
 ]
 
 
@@ -158,6 +158,8 @@ def lib():
     L.pp_rotate_iou_eval.argtypes = [ctypes.c_int, f32p, i64, f32p, i64, i32, f32p]
     L.pp_d3_box_overlap.argtypes = [ctypes.c_int, vp, i64, vp, i64, i32, vp]
     L.pp_head_loss.argtypes = [vp, vp, f32p, i32, ctypes.POINTER(PPLossConfig), f32p, f32p]
+    L.pp_adamw_step_device.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, i64, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_float, ctypes.c_float, ctypes.c_float]
     for name in EXPORTS:
         fn = getattr(L, name)  # raises AttributeError if the symbol is not exported
         if name not in ("pp_last_error", "pp_layer_tag"):

@@ -1262,6 +1262,15 @@ int pp_head_loss(pp_handle e, const int32_t* labels, const float* reg_targets, i
     return PP_OK;
 }
 
+int pp_adamw_step_device(int device, void* stream, float* params, const float* grads, float* m, float* v,
+                         int64_t n, float lr_t, float beta1, float beta2, float epsilon, float weight_decay) {
+    if (n < 0 || (n > 0 && (!params || !grads || !m || !v))) return fail(nullptr, PP_ERR_ARG, "pp_adamw_step_device: bad argument");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, PP_ERR_HIP, "pp_adamw_step_device: hipSetDevice(%d) failed", device);
+    launch_adamw(params, grads, m, v, n, lr_t, beta1, beta2, epsilon, weight_decay, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return fail(nullptr, PP_ERR_HIP, "pp_adamw_step_device: launch failed");
+    return PP_OK;
+}
+
 int pp_device_info(pp_handle e, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes) {
     if (!e) return PP_ERR_ARG;
     hipDeviceProp_t prop;

@@ -141,6 +141,10 @@ struct LossParams {
 int loss_blocks(int npx);
 int launch_head_loss(const LossParams& p, hipStream_t s);   // 0 or PP_ERR_UNSUPPORTED (anchors per pixel > 3)
 
+// optim.hip: AdamW update of one flat parameter buffer
+void launch_adamw(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                  float eps, float wd, hipStream_t s);
+
 // rotate_iou.hip: rotated-box overlaps of the AP evaluator
 void launch_riou_corners(const float* boxes, int64_t n, float* corners, hipStream_t s);
 void launch_riou_pairs(const float* bc, int64_t N, const float* qc, int64_t K, int criterion, float* out, hipStream_t s);

@@ -235,6 +235,14 @@ typedef struct pp_loss_config {
 int pp_head_loss(pp_handle h, const int32_t* labels, const float* reg_targets, int32_t batch,
                  const pp_loss_config* cfg, float* losses, float* head_grad);
 
+/* Replaces optimizer.apply_gradients for one flat float32 parameter buffer (train.py:228-239, :301:
+ * tfa.optimizers.AdamW over tf.keras Adam): var -= weight_decay * var; m, v moments; var -= lr_t * m /
+ * (sqrt(v) + epsilon) with lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) computed by the caller (t = step + 1,
+ * lr from the ExponentialDecay schedule).  DEVICE pointers (params, grads, m, v: n floats each, on `device`);
+ * `stream` is a hipStream_t or NULL; asynchronous on that stream.  Stateless. */
+int pp_adamw_step_device(int device, void* stream, float* params, const float* grads, float* m, float* v,
+                         int64_t n, float lr_t, float beta1, float beta2, float epsilon, float weight_decay);
+
 /* Device properties for reports: name (<=255 chars), CU count, bytes of HBM. */
 int pp_device_info(pp_handle h, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes);
 
