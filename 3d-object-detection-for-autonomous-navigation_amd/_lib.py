@@ -104,10 +104,16 @@ def build(force=False, verbose=False):
     """Compiles every HIP source for gfx950 into <package>/libpp_hip.so."""
     if not force and not needs_build():
         return SO_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", SO_PATH] + [os.path.join(_CSRC, s) for s in SOURCES]
+    tmp = f"{SO_PATH}.{os.getpid()}.tmp.so"      # atomic: a concurrent loader never sees a half-written library
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(_CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, SO_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return SO_PATH
 
 
