@@ -259,7 +259,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
                         }
                     }
                     if (act) {
-                        int* hp = &s_hist[d * VWAVES + wave];
+                        int* hp = &s_hist[wave * NB + d];   // [wave][digit]: the lanes of a wave spread over the banks
                         rank[t] = *reinterpret_cast<volatile int*>(hp) + __popcll(peers & lt);
                         if ((peers & lt) == 0ull) atomicAdd(hp, __popcll(peers));   // lowest lane of the group
                     }
@@ -271,19 +271,25 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
                 const int per = (E + VT - 1) / VT;
                 const int e0 = tid * per;
                 int local = 0;
+                // scan order is digit-major, wave-minor (entry e = digit * VWAVES + wave), storage is [wave][digit]
                 for (int q = 0; q < per; ++q)
-                    if (e0 + q < E) local += s_hist[e0 + q];
+                    if (e0 + q < E) local += s_hist[((e0 + q) % VWAVES) * NB + (e0 + q) / VWAVES];
                 int total;
                 int run = block_excl_scan(local, s_tmp, total);
                 for (int q = 0; q < per; ++q)
-                    if (e0 + q < E) { int t = s_hist[e0 + q]; s_hist[e0 + q] = run; run += t; }
+                    if (e0 + q < E) {
+                        int* hp = &s_hist[((e0 + q) % VWAVES) * NB + (e0 + q) / VWAVES];
+                        const int t = *hp;
+                        *hp = run;
+                        run += t;
+                    }
             }
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < VL_PPT; ++t) {
                 if (wbeg + t * 64 + lane < wend) {
                     const unsigned d = (ev[t] >> shift) & dmask;
-                    dk[s_hist[d * VWAVES + wave] + rank[t]] = ev[t];
+                    dk[s_hist[wave * NB + d] + rank[t]] = ev[t];
                 }
             }
             __syncthreads();
@@ -392,20 +398,25 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
         __syncthreads();
         for (int t0 = wbeg; t0 < wend; t0 += 64) {
             const int j = t0 + lane;
-            if (j < wend) atomicAdd(&s_hist[((sk[j] >> shift) & dmask) * VWAVES + wave], 1);
+            if (j < wend) atomicAdd(&s_hist[wave * NB + ((sk[j] >> shift) & dmask)], 1);   // [wave][digit]: banks by digit
         }
         __syncthreads();
-        {   // exclusive scan over (digit major, wave minor)
+        {   // exclusive scan over (digit major, wave minor): entry e = digit * VWAVES + wave, stored at [wave][digit]
             const int E = NB * VWAVES;
             const int per = (E + VT - 1) / VT;
             const int e0 = tid * per;
             int local = 0;
             for (int q = 0; q < per; ++q)
-                if (e0 + q < E) local += s_hist[e0 + q];
+                if (e0 + q < E) local += s_hist[((e0 + q) % VWAVES) * NB + (e0 + q) / VWAVES];
             int total;
             int run = block_excl_scan(local, s_tmp, total);
             for (int q = 0; q < per; ++q)
-                if (e0 + q < E) { int t = s_hist[e0 + q]; s_hist[e0 + q] = run; run += t; }
+                if (e0 + q < E) {
+                    int* hp = &s_hist[((e0 + q) % VWAVES) * NB + (e0 + q) / VWAVES];
+                    const int t = *hp;
+                    *hp = run;
+                    run += t;
+                }
         }
         __syncthreads();
         for (int t0 = wbeg; t0 < wend; t0 += 64) {
@@ -421,11 +432,11 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
                 peers &= one ? bb : ~bb;
             }
             if (act) {
-                const int basep = vhist[d * VWAVES + wave];
+                const int basep = vhist[wave * NB + d];
                 const int pos = basep + __popcll(peers & lt);
                 dk[pos] = k;
                 dv[pos] = v;
-                if (lane == 63 - __clzll(peers)) vhist[d * VWAVES + wave] = basep + __popcll(peers);
+                if (lane == 63 - __clzll(peers)) vhist[wave * NB + d] = basep + __popcll(peers);
             }
         }
         __syncthreads();
