@@ -233,9 +233,14 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int ncanvas = p.ny * p.nx;
-    const int cell0 = (blockIdx.x * 4 + wave) * PFN2_CW;
-    if (cell0 >= ncanvas) return;
-    const int ncells = min(PFN2_CW, ncanvas - cell0);
+    // a wave's PFN2_CW cells are spread over the map (cell = wave id + c * waves per frame), not contiguous:
+    // points cluster (a person is a few dozen neighbouring cells with up to T points each), and a wave that owned
+    // eight neighbouring crowded cells ran 30x longer than the average one -- the kernel's duration was its tail
+    // (sparse canvas: contiguous cells instead -- on a mostly empty grid whole waves then have nothing to do)
+    const int NW = p.sparse ? 1 : gridDim.x * 4;      // cell stride: waves per frame (NW * PFN2_CW >= ncanvas) or 1
+    const int wid = p.sparse ? (blockIdx.x * 4 + wave) * PFN2_CW : blockIdx.x * 4 + wave;   // first cell
+    if (wid >= ncanvas) return;
+    const int ncells = min(PFN2_CW, (ncanvas - wid + NW - 1) / NW);
     const int nz = p.nz;
     const int NS = ncells * nz;                       // slots of this wave (<= 64, checked by the launcher)
     const int C = p.C, T = p.T;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     if (lane < NS) {
         const int c = lane / nz, z = lane - c * nz;
         slot_cell = c;
-        pid = p.cellmap[((size_t)b * nz + z) * ncanvas + cell0 + c];
+        pid = p.cellmap[((size_t)b * nz + z) * ncanvas + wid + c * NW];
     }
     // sparse canvas: most waves of a mostly empty grid have nothing to write -- leave before any other work
     if (p.sparse && __ballot(pid >= 0) == 0ull) return;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
             start = ps[pid];
             cnt = min(ps[pid + 1] - start, T);
         }
-        const int cell = cell0 + c;
+        const int cell = wid + c * NW;
         const int yi = cell / p.nx, xi = cell - yi * p.nx;
         slot_cx = __fadd_rn(__fmul_rn((float)xi, p.vx), p.x_off);      // model/pointpillars.py:156-171
         slot_cy = __fadd_rn(__fmul_rn((float)yi, p.vy), p.y_off);
@@ -317,7 +322,8 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     };
 
     // ---- (3) walk the stream ----
-    float* cbase = p.canvas + ((size_t)b * ncanvas + cell0) * C;
+    float* cbase = p.canvas + ((size_t)b * ncanvas + wid) * C;
+    const size_t cstep = (size_t)NW * C;              // floats between two cells of this wave
     float acc[CPL], m[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) { acc[q] = 0.f; m[q] = -3.0e38f; }
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
         // sparse canvas: cells without a pillar are not written at all (the first layer looks the cell up in
         // the cell map and reads zeros); writing the zeros of an almost empty grid is most of the traffic
         if (ch_ok && (cell_dirty || !p.sparse)) {
-            float* dst = cbase + (size_t)c * C + ch0;
+            float* dst = cbase + (size_t)c * cstep + ch0;
             if constexpr (CPL == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             else if constexpr (CPL == 2) *reinterpret_cast<float2*>(dst) = make_float2(acc[0], acc[1]);
             else dst[0] = acc[0];
