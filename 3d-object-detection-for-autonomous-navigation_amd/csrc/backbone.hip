@@ -1851,7 +1851,7 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
         int wps;   // workgroups per CU of the instantiation launch_layer picks (launch_u<NT, S, WPS, WPB>)
         if (L.stride == 1) wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 3 : 4);
         else wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 2 : (unt == 64 ? 3 : 4));
-        snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d,%d>", unt, L.stride, wps, bf ? 1 : 0);
+        snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d,%d,%d>", unt, L.stride, wps, bf ? 1 : 0, (bf && L.d_occ) ? 1 : 0);
     } else if (deconv_uniform(L, 0) && deconv_k4_runs(L, layer_rows(L, batch), 0)) {
         snprintf(buf, sizeof(buf), "k_deconv_k4<%d>", nt);
     } else if (deconv_uniform(L, 0)) {

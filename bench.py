@@ -122,6 +122,16 @@ def cpu_baseline(pp, d, weights, frames, calib, budget_s=20.0):
                       f"C voxeliser + numpy PFN + torch-CPU fp32 backbone ({cores} threads) + numpy predict"}
 
 
+def is_split_kernel(sym):
+    """Does this GEMM kernel run on the bf16 matrix pipe with split operands?  k_sep_u<NT,S,WPS,PREC,OCC>: PREC."""
+    if sym.startswith(("k_deconv_u", "k_deconv_k4", "k_sep_k4")):
+        return True
+    if sym.startswith("k_sep_u<"):
+        params = sym[sym.index("<") + 1:sym.rindex(">")].split(",")
+        return len(params) > 3 and params[3].strip() == "1"
+    return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,8 +271,7 @@ def main():
         flops_launch = sum(lf[n] for n in mine) / launches[dominant]
         bytes_launch = sum(lb[n] for n in mine) / launches[dominant]
         avg_ms = kernel_ms[dominant] / launches[dominant]
-        split = (dominant.startswith(("k_deconv_u", "k_deconv_k4", "k_sep_k4")) or
-                 (dominant.startswith("k_sep_u") and dominant.endswith(",1>")))
+        split = is_split_kernel(dominant)
         mfma_peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_TERMS if split else F32_MFMA_PEAK_TFLOPS
         tf = flops_launch / (avg_ms * 1e-3) / 1e12
         gbs = bytes_launch / (avg_ms * 1e-3) / 1e9
@@ -333,8 +342,7 @@ def main():
     for layer, (tms, cnt, sym) in iso_layer.items():
         t = tms / cnt * 1e-3
         if layer in lf:
-            split = (sym.startswith(("k_deconv_u", "k_deconv_k4", "k_sep_k4")) or
-                     (sym.startswith("k_sep_u") and sym.endswith(",1>")))
+            split = is_split_kernel(sym)
             peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_TERMS if split else F32_MFMA_PEAK_TFLOPS
             roofs[layer] = {"kernel": sym, "ms": round(t * 1e3, 4), "GBps": round(lbytes[layer] / t / 1e9, 1),
                             "frac_hbm": round(lbytes[layer] / t / 1e9 / HBM_PEAK_GBS, 3),
