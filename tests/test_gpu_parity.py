@@ -490,3 +490,73 @@ def test_bench_two_rank_path_rehearsal(hip_lib):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
     assert d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
+
+
+def _random_config(rng, B):
+    """A small reference-schema config drawn at random: grid, first stride, z cells, channel widths, layer counts,
+    point features, pillar capacity."""
+    import copy
+    cfg = copy.deepcopy(pp_mod().config.pedestrian_d435i_config(B))
+    s1 = int(rng.choice([1, 2]))
+    nx, ny = 4 * s1 * int(rng.integers(3, 7)), 4 * s1 * int(rng.integers(2, 6))
+    v = 0.08
+    nz2 = bool(rng.integers(0, 2))
+    zr = (-3.0, 3.0) if nz2 else (-3.0, 1.0)
+    x0, y0 = 0.0, -ny * v / 2
+    F = int(rng.choice([3, 4]))
+    C = int(rng.choice([32, 64, 128]))
+    filters = [int(rng.choice([32, 64])), int(rng.choice([32, 64])), int(rng.choice([64, 128]))]
+    up = int(rng.choice([32, 64, 128]))
+    cfg["eval_input_reader"].update(batch_size=B, feature_map_size=[1, ny // s1, nx // s1], num_point_features=F)
+    s = cfg["model"]["second"]
+    s["num_point_features"] = F
+    s["voxel_generator"].update(point_cloud_range=[x0, y0, zr[0], x0 + nx * v, y0 + ny * v, zr[1]],
+                                max_number_of_points_per_voxel=int(rng.choice([5, 12, 50])),
+                                max_number_of_voxels=int(rng.choice([150, 2000])))
+    s["voxel_feature_extractor"]["num_filters"] = C
+    s["rpn"].update(layer_nums=[int(rng.integers(1, 3)) for _ in range(3)], layer_strides=[s1, 2, 2],
+                    num_filters=filters, upsample_strides=[1, 2, 4], num_upsample_filters=[up] * 3)
+    s["target_assigner"]["anchor_generators"]["anchor_generator_stride"].update(
+        strides=[v * s1, v * s1, 0.0], offsets=[x0 + v * s1, y0, -1.465])
+    return cfg
+
+
+def pp_mod():
+    import pp_amd
+    return pp_amd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110])
+def test_random_small_configs_end_to_end(seed):
+    """Configurations the shipped YAML does not use (first stride 2, one z cell, 4 point features, narrow layers,
+    small pillar caps that trigger the max_voxels break): whole path against the oracle."""
+    pp = pp_mod()
+    rng = np.random.default_rng(seed)
+    B = 2
+    cfg = _random_config(rng, B)
+    eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=8192)
+    d = eng.d
+    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=seed))
+    eng.load_weights(w)
+    lo, hi = d.pc_range[:3], d.pc_range[3:]
+    frames = []
+    for n in (int(rng.integers(800, 4000)), int(rng.integers(1, 600))):
+        xyz = rng.uniform(lo - 0.2, hi + 0.2, (n, 3))
+        extra = rng.uniform(0, 1, (n, d.num_point_features - 3))
+        frames.append(np.concatenate([xyz, extra], axis=1).astype(np.float32))
+    rect, trv, p2 = pp.synth.default_calib()
+    ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
+    dets, n = eng.detect(frames, np.stack([rect] * B), np.stack([trv] * B))
+    im = eng.intermediates()
+    for b in range(B):
+        fr = ref["frames"][b]
+        P = fr["coordinates"].shape[0]
+        assert im["n_pillars"][b] == P and np.array_equal(im["coors"][b, :P], fr["coordinates"])
+        assert np.array_equal(im["num_points"][b, :P], fr["num_points"])
+        assert np.array_equal(im["anchors_mask"][b].astype(bool), fr["anchors_mask"])
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=TOL, atol=TOL)
+    got = [pp.VoxelNet._to_dict(dets[b], int(n[b]), b) for b in range(B)]
+    _assert_dets(got, ref["dets"])
+    eng.close()
