@@ -560,3 +560,24 @@ def test_random_small_configs_end_to_end(seed):
     got = [pp.VoxelNet._to_dict(dets[b], int(n[b]), b) for b in range(B)]
     _assert_dets(got, ref["dets"])
     eng.close()
+
+
+@pytest.mark.gpu
+def test_small_and_large_batch_kernels_agree(pp, engines):
+    """A frame alone (split-K kernels k_sep_k4 / k_deconv_k4) and the same frame inside a 64-frame batch
+    (persistent k_sep_u / k_deconv_u): the head maps agree far inside the parity tolerance and the detections
+    are the same boxes."""
+    big = engines("net-A64", pp.config.pedestrian_d435i_config(64), max_batch=64, weights_seed=7)
+    one = engines("net-A1-w7", pp.config.pedestrian_d435i_config(1), max_batch=1, weights_seed=7)
+    assert any(t.startswith("k_sep_k4") for t in one.layer_tags()) and any(t.startswith("k_sep_u") for t in big.layer_tags())
+    frames = [pp.synth.d435i_cloud(400 + i) for i in range(64)]
+    dets64, n64 = big.detect(frames)
+    im64 = big.intermediates()
+    for i in (0, 17, 63):
+        d1, n1 = one.detect([frames[i]])
+        im1 = one.intermediates()
+        for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+            np.testing.assert_allclose(im1[k][0], im64[k][i], rtol=2e-5, atol=2e-5)
+        assert n1[0] == n64[i]
+        assert np.array_equal(d1[0]["anchor_index"][:n1[0]], dets64[i]["anchor_index"][:n64[i]])
+        np.testing.assert_allclose(d1[0]["score"][:n1[0]], dets64[i]["score"][:n64[i]], rtol=1e-5, atol=1e-6)
