@@ -766,16 +766,6 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
 #endif
     const int total = ntl * nchunks;                   // K-chunks in this workgroup's stream (>= 2: cin >= 32)
 
-    // depthwise taps -> LDS as [channel group of 4][9 taps][4 channels]: the 9 tap vectors of a lane's channel
-    // group are 16 bytes apart (immediate offsets on one base address, which moves 576 bytes per K-chunk)
-    {
-        const int ngrp = cin / 4;
-        for (int e = tid; e < 9 * ngrp; e += 256) {
-            const int t = e / ngrp, g4 = e - t * ngrp;
-            reinterpret_cast<float4*>(sDW)[g4 * 9 + t] = reinterpret_cast<const float4*>(a.dw)[e];
-        }
-    }
-
     // ---- staging role: lane (q, c4) owns output pixels pw + 2q, +1 and channels 4*c4..+3 of a chunk ----
     const int c4 = lane & 3, q = lane >> 2;
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
@@ -863,6 +853,16 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     U_TILE_OFFSETS(ld_tile)
     U_LOAD_CHUNK(0)
     ld_kc = 1;                           // nchunks >= 2 (cin >= 32, checked by the launcher)
+    // depthwise taps -> LDS as [channel group of 4][9 taps][4 channels]: the 9 tap vectors of a lane's channel
+    // group are 16 bytes apart (immediate offsets on one base address, which moves 576 bytes per K-chunk).
+    // Staged AFTER the first window loads have been issued: the two memory round trips of the prologue overlap
+    {
+        const int ngrp = cin / 4;
+        for (int e = tid; e < 9 * ngrp; e += 256) {
+            const int t = e / ngrp, g4 = e - t * ngrp;
+            reinterpret_cast<float4*>(sDW)[g4 * 9 + t] = reinterpret_cast<const float4*>(a.dw)[e];
+        }
+    }
 
     f32x16 acc[NTILES];
 #pragma unroll
@@ -1088,13 +1088,6 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
     const int cin = a.cin;
     const int niter = cin / (KCH * 4);          // chunks per wave (>= 1, checked by the launcher)
 
-    {
-        const int ngrp = cin / 4;
-        for (int e = tid; e < 9 * ngrp; e += 256) {
-            const int t = e / ngrp, g4 = e - t * ngrp;
-            reinterpret_cast<float4*>(sDW)[g4 * 9 + t] = reinterpret_cast<const float4*>(a.dw)[e];
-        }
-    }
     const int c4 = lane & 3, q = lane >> 2;
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc((const void*)a.wt16);
@@ -1161,6 +1154,13 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
             *reinterpret_cast<float4*>(sBw + (BUF) * SB + bdst[r]) = rb[r];                              \
     }
     K4_LOAD(wave)
+    {   // depthwise taps -> LDS, after the first window loads are in flight (one prologue round trip, not two)
+        const int ngrp = cin / 4;
+        for (int e = tid; e < 9 * ngrp; e += 256) {
+            const int t = e / ngrp, g4 = e - t * ngrp;
+            reinterpret_cast<float4*>(sDW)[g4 * 9 + t] = reinterpret_cast<const float4*>(a.dw)[e];
+        }
+    }
     f32x16 acc[NTILES];
 #pragma unroll
     for (int n = 0; n < NTILES; ++n)
@@ -1380,12 +1380,6 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
         s_opix[SLOT][tid] = (b_ * a.px_h * a.k + y_ * a.k) * (a.px_w * a.k) + x_ * a.k; \
     }
     D_FILL_OPIX(first, 0)
-    if (tid < NT) s_bias[tid] = a.bias[cbase + tid];
-    if (heads) {   // this branch's head-kernel slice, three bf16 pieces, into LDS once
-        for (int e = tid; e < SHW / 4; e += 256)   // 16-byte halves swapped on odd groups of 8 columns (bank conflicts)
-            reinterpret_cast<float4*>(sHW)[e ^ ((e >> 4) & 1)] = reinterpret_cast<const float4*>(a.head_wt16)[e];
-        if (tid < PP_HEAD_COLS) s_hbias[tid] = a.head_bias[tid];
-    }
 
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt16);
@@ -1437,6 +1431,14 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
     D_LOAD_A(rc0, rc1)                   // position 1 (total >= 2)
     D_LOAD_B(0)
     int lb_kc = 1;                       // chunk index of the next weight tile to load
+    // bias and this branch's head-kernel slice -> LDS, after the first operand loads are in flight (the
+    // prologue's memory round trips overlap)
+    if (tid < NT) s_bias[tid] = a.bias[cbase + tid];
+    if (heads) {   // three bf16 pieces; 16-byte halves swapped on odd groups of 8 columns (bank conflicts)
+        for (int e = tid; e < SHW / 4; e += 256)
+            reinterpret_cast<float4*>(sHW)[e ^ ((e >> 4) & 1)] = reinterpret_cast<const float4*>(a.head_wt16)[e];
+        if (tid < PP_HEAD_COLS) s_hbias[tid] = a.head_bias[tid];
+    }
 
     int mm_tile = first, mm_kc = 0, mm_slot = 0;
     __syncthreads();                     // bias / head weights / opix table visible
@@ -1533,12 +1535,6 @@ __global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
     const bool heads = a.head_mode != 0;
     float* const sBw = sR + wave * SB;
 
-    if (tid < NT) s_bias[tid] = a.bias[cbase + tid];
-    if (heads) {
-        for (int e = tid; e < SHW / 4; e += 256)
-            reinterpret_cast<float4*>(sHW)[e ^ ((e >> 4) & 1)] = reinterpret_cast<const float4*>(a.head_wt16)[e];
-        if (tid < PP_HEAD_COLS) s_hbias[tid] = a.head_bias[tid];
-    }
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt16);
     const int pix = blockIdx.x * 32 + r32;
@@ -1568,6 +1564,13 @@ __global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
     float4 rb[NBL];
 #pragma unroll
     for (int r = 0; r < NBL; ++r) rb[r] = buf_load16(rs_wt, boff[r], (unsigned)wave * bstep);
+    // bias / head weights -> LDS after the operand loads are in flight (visible at the first barrier below)
+    if (tid < NT) s_bias[tid] = a.bias[cbase + tid];
+    if (heads) {
+        for (int e = tid; e < SHW / 4; e += 256)
+            reinterpret_cast<float4*>(sHW)[e ^ ((e >> 4) & 1)] = reinterpret_cast<const float4*>(a.head_wt16)[e];
+        if (tid < PP_HEAD_COLS) s_hbias[tid] = a.head_bias[tid];
+    }
     f32x16 acc[NTILES];
 #pragma unroll
     for (int n = 0; n < NTILES; ++n)
