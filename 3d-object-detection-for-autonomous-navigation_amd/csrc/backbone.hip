@@ -835,7 +835,12 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
 #define U_LOAD_ACT(KCIDX, RIN)                                                                           \
     {                                                                                                    \
         const unsigned so_ = (unsigned)(KCIDX) * (KCH * 4);                                              \
-        _Pragma("unroll") for (int e = 0; e < NLD; ++e) RIN[e] = buf_load16(rs_in, aoff[e], so_);        \
+        _Pragma("unroll") for (int e = 0; e < NLD; ++e) {                                                \
+            /* diagnostic build, bit 256: the two outer window columns are not loaded (half the window   \
+               traffic of a stride-1 layer; wrong results, timing only) */                               \
+            if ((dbg & 256) && (e % WW == 0 || e % WW == WW - 1)) RIN[e] = make_float4(0.f, 0.f, 0.f, 0.f); \
+            else RIN[e] = buf_load16(rs_in, aoff[e], so_);                                               \
+        }                                                                                                \
     }
 #define U_LOAD_WT(KCIDX)                                                                                 \
     {                                                                                                    \

@@ -3,7 +3,8 @@
     python tools/layer_bench.py [--batch 64] [--layers 5,7] [--ablate 0,1,2,4,8]
 ablate bits: 16 / 32 force the uniform-wave / producer-consumer separable kernel, 2048 / 4096 force the
 split-precision bf16 / fp32 MFMA instantiation; in a -DPP_KERNEL_STAMPS build of libpp_hip.so also 1 no MFMA,
-2 no depthwise FMAs, 4 no epilogue stores, 8 no global activation loads, 64 phase stamps (PP_STAMPS_OUT).
+2 no depthwise FMAs, 4 no epilogue stores, 8 no global activation loads, 256 outer window columns not loaded
+(half the window traffic of a stride-1 layer), 64 phase stamps (PP_STAMPS_OUT).
 """
 import argparse
 import os
