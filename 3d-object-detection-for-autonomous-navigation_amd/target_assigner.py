@@ -91,81 +91,81 @@ def unmap(data, count, inds, fill=0):
     return ret
 
 
+def _match(iou, gt_classes, hi_thr, lo_thr):
+    """The matching rule on an [n_anchor, n_gt] similarity matrix.  Returns (labels, gt index per anchor (-1: none),
+    best overlap per anchor, background anchor indices, forced anchors, their boxes)."""
+    n = iou.shape[0]
+    labels = np.full((n,), -1, dtype=np.int32)
+    owner = np.full((n,), -1, dtype=np.int32)
+    best_gt = iou.argmax(axis=1)                       # per anchor: its best box ...
+    best_iou = iou[np.arange(n), best_gt]              # ... and how well it fits
+    top_anchor = iou.argmax(axis=0)                    # per box: an anchor with its best overlap
+    top_iou = iou[top_anchor, np.arange(iou.shape[1])]
+    top_iou[top_iou == 0] = -1                         # a box that touches no anchor forces nothing
+    forced = np.where(iou == top_iou)[0]               # every anchor tying for a box's best overlap
+    forced_gt = best_gt[forced]
+    labels[forced] = gt_classes[forced_gt]
+    owner[forced] = forced_gt
+    good = best_iou >= hi_thr
+    labels[good] = gt_classes[best_gt[good]]
+    owner[good] = best_gt[good]
+    background = np.where(best_iou < lo_thr)[0]
+    return labels, owner, best_gt, best_iou, background, forced, forced_gt
+
+
 def create_target_np(all_anchors, gt_boxes, prune_anchor_fn, gt_classes, matched_threshold, unmatched_threshold,
                      positive_fraction, rpn_batch_size, norm_by_num_examples, box_code_size,
                      bbox_inside_weight=None):
-    total_anchors = all_anchors.shape[0]
-    if prune_anchor_fn is not None:
-        inds_inside = prune_anchor_fn(all_anchors)
-        anchors = all_anchors[inds_inside, :]
+    """load_data.py:331-532 (same arguments and returned keys)."""
+    total = all_anchors.shape[0]
+    keep = prune_anchor_fn(all_anchors) if prune_anchor_fn is not None else None
+    anchors = all_anchors if keep is None else all_anchors[keep, :]
+    if keep is not None:
         if not isinstance(matched_threshold, float):
-            matched_threshold = matched_threshold[inds_inside]
+            matched_threshold = matched_threshold[keep]
         if not isinstance(unmatched_threshold, float):
-            unmatched_threshold = unmatched_threshold[inds_inside]
-    else:
-        anchors = all_anchors
-        inds_inside = None
-    num_inside = len(inds_inside) if inds_inside is not None else total_anchors
+            unmatched_threshold = unmatched_threshold[keep]
+    n = anchors.shape[0] if keep is None else len(keep)
     if gt_classes is None:
         gt_classes = np.ones([gt_boxes.shape[0]], dtype=np.int32)
-    labels = np.full((num_inside,), -1, dtype=np.int32)
-    gt_ids = np.full((num_inside,), -1, dtype=np.int32)
-    have = len(gt_boxes) > 0 and anchors.shape[0] > 0
-    if have:
-        overlap = similarity_fn(anchors, gt_boxes)
-        anchor_to_gt_argmax = overlap.argmax(axis=1)
-        anchor_to_gt_max = overlap[np.arange(num_inside), anchor_to_gt_argmax]
-        gt_to_anchor_argmax = overlap.argmax(axis=0)
-        gt_to_anchor_max = overlap[gt_to_anchor_argmax, np.arange(overlap.shape[1])]
-        gt_to_anchor_max[gt_to_anchor_max == 0] = -1           # a box that touches no anchor forces nothing
-        anchors_with_max_overlap = np.where(overlap == gt_to_anchor_max)[0]
-        gt_inds_force = anchor_to_gt_argmax[anchors_with_max_overlap]
-        labels[anchors_with_max_overlap] = gt_classes[gt_inds_force]
-        gt_ids[anchors_with_max_overlap] = gt_inds_force
-        pos_inds = anchor_to_gt_max >= matched_threshold
-        gt_inds = anchor_to_gt_argmax[pos_inds]
-        labels[pos_inds] = gt_classes[gt_inds]
-        gt_ids[pos_inds] = gt_inds
-        bg_inds = np.where(anchor_to_gt_max < unmatched_threshold)[0]
+    matched = len(gt_boxes) > 0 and anchors.shape[0] > 0
+    if matched:
+        labels, owner, best_gt, best_iou, background, forced, forced_gt = _match(
+            similarity_fn(anchors, gt_boxes), gt_classes, matched_threshold, unmatched_threshold)
     else:
-        bg_inds = np.arange(num_inside)
-    fg_inds = np.where(labels > 0)[0]
-    fg_max_overlap = anchor_to_gt_max[fg_inds] if have else None
-    gt_pos_ids = gt_ids[fg_inds]
+        labels = np.full((n,), -1, dtype=np.int32)
+        owner = np.full((n,), -1, dtype=np.int32)
+        background = np.arange(n)
+    positives = np.where(labels > 0)[0]
+    positive_overlap = best_iou[positives] if matched else None
+    positive_gt = owner[positives]
     if positive_fraction is not None:
-        num_fg = int(positive_fraction * rpn_batch_size)
-        if len(fg_inds) > num_fg:
-            disable_inds = npr.choice(fg_inds, size=(len(fg_inds) - num_fg), replace=False)
-            labels[disable_inds] = -1
-            fg_inds = np.where(labels > 0)[0]
-        num_bg = rpn_batch_size - np.sum(labels > 0)
-        if len(bg_inds) > num_bg:
-            enable_inds = bg_inds[npr.randint(len(bg_inds), size=num_bg)]
-            labels[enable_inds] = 0
-        bg_inds = np.where(labels == 0)[0]
+        # subsampling with numpy's global generator, in the reference's order of draws
+        quota = int(positive_fraction * rpn_batch_size)
+        if len(positives) > quota:
+            labels[npr.choice(positives, size=(len(positives) - quota), replace=False)] = -1
+            positives = np.where(labels > 0)[0]
+        room = rpn_batch_size - np.sum(labels > 0)
+        if len(background) > room:
+            labels[background[npr.randint(len(background), size=room)]] = 0
+    elif not matched:
+        labels[:] = 0
     else:
-        if not have:
-            labels[:] = 0
-        else:
-            labels[bg_inds] = 0
-            labels[anchors_with_max_overlap] = gt_classes[gt_inds_force]   # forced matches win over background
-    bbox_targets = np.zeros((num_inside, box_code_size), dtype=all_anchors.dtype)
-    if have:
-        bbox_targets[fg_inds, :] = box_encoding_fn(gt_boxes[anchor_to_gt_argmax[fg_inds], :], anchors[fg_inds, :])
-    bbox_outside_weights = np.zeros((num_inside,), dtype=all_anchors.dtype)
-    if norm_by_num_examples:
-        num_examples = np.maximum(1.0, np.sum(labels >= 0))
-        bbox_outside_weights[labels > 0] = 1.0 / num_examples
-    else:
-        bbox_outside_weights[labels > 0] = 1.0
-    if inds_inside is not None:
-        labels = unmap(labels, total_anchors, inds_inside, fill=-1)
-        bbox_targets = unmap(bbox_targets, total_anchors, inds_inside, fill=0)
-        bbox_outside_weights = unmap(bbox_outside_weights, total_anchors, inds_inside, fill=0)
+        labels[background] = 0
+        labels[forced] = gt_classes[forced_gt]          # forced matches win over background
+    targets = np.zeros((n, box_code_size), dtype=all_anchors.dtype)
+    if matched:
+        targets[positives, :] = box_encoding_fn(gt_boxes[best_gt[positives], :], anchors[positives, :])
+    weights = np.zeros((n,), dtype=all_anchors.dtype)
+    weights[labels > 0] = 1.0 / np.maximum(1.0, np.sum(labels >= 0)) if norm_by_num_examples else 1.0
+    if keep is not None:
+        labels = unmap(labels, total, keep, fill=-1)
+        targets = unmap(targets, total, keep, fill=0)
+        weights = unmap(weights, total, keep, fill=0)
     return {
-        "labels": labels, "bbox_targets": bbox_targets, "bbox_outside_weights": bbox_outside_weights,
-        "assigned_anchors_overlap": fg_max_overlap, "positive_gt_id": gt_pos_ids,
-        "assigned_anchors_inds": inds_inside[fg_inds] if inds_inside is not None else fg_inds,
+        "labels": labels, "bbox_targets": targets, "bbox_outside_weights": weights,
+        "assigned_anchors_overlap": positive_overlap, "positive_gt_id": positive_gt,
+        "assigned_anchors_inds": keep[positives] if keep is not None else positives,
     }
 
 
