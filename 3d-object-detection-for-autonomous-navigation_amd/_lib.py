@@ -13,7 +13,10 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 _INCLUDE = os.path.join(os.path.dirname(_PKG), "include", "pp_hip.h")
-SO_PATH = os.path.join(_PKG, "libpp_hip.so")
+# PP_HIP_LIB: load (and build into) another library file -- A/B builds of compile-time variants, e.g.
+#   PP_HIP_LIB=libpp_hip_f16.so PP_HIPCC_EXTRA="-DPP_SPLIT_MODE=1" python -c "import pp_amd; pp_amd._lib.build()"
+SO_PATH = os.path.join(_PKG, os.environ.get("PP_HIP_LIB", "libpp_hip.so"))
+_VARIANT = os.path.splitext(os.path.basename(SO_PATH))[0]
 SOURCES = ["pp_api.hip", "voxelize.hip", "pfn.hip", "anchor_mask.hip", "backbone.hip", "postprocess.hip",
            "rotate_iou.hip", "loss.hip", "optim.hip"]
 # -fno-slp-vectorize: keeps f32 FMAs as v_fma_f32; the SLP vectoriser's v_pk_fma_f32 is slow on a SIMD
@@ -24,7 +27,8 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
 EXPORTS = [
     "pp_abi_version", "pp_create", "pp_destroy", "pp_last_error", "pp_set_weight", "pp_finalize_weights",
     "pp_set_anchors", "pp_points_to_voxel", "pp_anchor_mask", "pp_forward_voxels", "pp_predict",
-    "pp_upload_points", "pp_upload_points_device", "pp_set_calib", "pp_detect_async", "pp_sync",
+    "pp_upload_points", "pp_upload_points_async", "pp_host_alloc", "pp_host_free", "pp_upload_points_device",
+    "pp_current_batch", "pp_set_calib", "pp_detect_async", "pp_sync",
     "pp_get_detections", "pp_detect", "pp_fetch_intermediates", "pp_set_profiling", "pp_get_kernel_times",
     "pp_timer_start", "pp_timer_stop", "pp_device_info", "pp_bench_layer", "pp_layer_count", "pp_layer_tag",
     "pp_rotate_iou_eval", "pp_d3_box_overlap", "pp_head_loss", "pp_adamw_step_device",
@@ -53,6 +57,8 @@ class PPConfig(ctypes.Structure):
         ("anchor_area_threshold", ctypes.c_float),
         ("max_batch", ctypes.c_int32),
         ("max_points_per_frame", ctypes.c_int32),
+        ("use_direction_classifier", ctypes.c_int32),
+        ("with_distance", ctypes.c_int32),
     ]
 
 
@@ -92,22 +98,57 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build libpp_hip.so")
 
 
+_OBJ = os.path.join(_CSRC, "_obj" if _VARIANT == "libpp_hip" else "_obj_" + _VARIANT)
+_EXTRA = os.environ.get("PP_HIPCC_EXTRA", "").split()
+
+
+def _deps():
+    return [os.path.join(_CSRC, "pp_common.h"), _INCLUDE]
+
+
 def needs_build():
     if not os.path.exists(SO_PATH):
         return True
     t = os.path.getmtime(SO_PATH)
-    deps = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(_CSRC, "pp_common.h"), _INCLUDE]
+    deps = [os.path.join(_CSRC, s) for s in SOURCES] + _deps()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile_one(src, verbose):
+    """One translation unit -> csrc/_obj/<name>.o (skipped when the object is newer than its inputs)."""
+    obj = os.path.join(_OBJ, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(_CSRC, src)
+    if os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [path] + _deps()):
+        return obj
+    tmp = f"{obj}.{os.getpid()}.tmp"
+    cmd = [_hipcc()] + [f for f in HIPCC_FLAGS if f != "-shared"] + _EXTRA + ["-c", "-o", tmp, path]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, obj)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return obj
+
+
 def build(force=False, verbose=False):
-    """Compiles every HIP source for gfx950 into <package>/libpp_hip.so."""
+    """Compiles every HIP source for gfx950 (one object per translation unit, in parallel) and links
+    <package>/libpp_hip.so."""
     if not force and not needs_build():
         return SO_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(_OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(_OBJ):
+            os.remove(os.path.join(_OBJ, f))
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda s: _compile_one(s, verbose), SOURCES))
     tmp = f"{SO_PATH}.{os.getpid()}.tmp.so"      # atomic: a concurrent loader never sees a half-written library
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(_CSRC, s) for s in SOURCES]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", tmp] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     try:
         subprocess.check_call(cmd)
         os.replace(tmp, SO_PATH)
@@ -144,7 +185,11 @@ def lib():
     L.pp_forward_voxels.argtypes = [vp, f32p, vp, vp, i64, i32, f32p, f32p, f32p, f32p, f32p]
     L.pp_predict.argtypes = [vp, f32p, f32p, f32p, vp, f32p, f32p, i32, vp, vp]
     L.pp_upload_points.argtypes = [vp, f32p, vp, i32]
-    L.pp_upload_points_device.argtypes = [vp, vp, vp, i32]
+    L.pp_upload_points_async.argtypes = [vp, vp, vp, i32]
+    L.pp_host_alloc.argtypes = [i64, ctypes.POINTER(vp)]
+    L.pp_host_free.argtypes = [vp]
+    L.pp_upload_points_device.argtypes = [vp, vp, vp, i32, vp]
+    L.pp_current_batch.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.pp_set_calib.argtypes = [vp, f32p, f32p, i32]
     L.pp_detect_async.argtypes = [vp]
     L.pp_sync.argtypes = [vp]

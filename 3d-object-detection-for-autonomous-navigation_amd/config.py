@@ -86,9 +86,11 @@ def pedestrian_d435i_config(batch_size=1, max_points=None, max_voxels=None):
     return cfg
 
 
-def kitti_shaped_config(batch_size=1):
+def kitti_shaped_config(batch_size=1, num_class=1):
     """cfg-K: KITTI-shaped grid reachable by config only (BASELINE.json configs[2]):
-    0.16 m pillars, 432x496 BEV, 4 point features, C=64, T=100, strides [2,2,2]."""
+    0.16 m pillars, 432x496 BEV, 4 point features, C=64, T=100, strides [2,2,2].
+    num_class=2: "Pedestrian+Cyclist" as SURVEY section 8a sizes it (2 anchors per location, 22 head channels:
+    both classes score every anchor, the label is the argmax)."""
     cfg = copy.deepcopy(_PEDESTRIAN_D435I)
     cfg["eval_input_reader"].update(batch_size=batch_size, num_point_features=4,
                                     feature_map_size=[1, 248, 216])
@@ -100,6 +102,9 @@ def kitti_shaped_config(batch_size=1):
         "max_number_of_voxels": 12000,
     }
     s["num_point_features"] = 4
+    s["num_class"] = int(num_class)
+    if num_class > 1:
+        cfg["eval_input_reader"]["desired_objects"] = ["Pedestrian", "Cyclist"][:num_class]
     s["voxel_feature_extractor"]["num_filters"] = 64
     s["rpn"].update(layer_strides=[2, 2, 2], upsample_strides=[1, 2, 4])
     s["target_assigner"]["anchor_generators"]["anchor_generator_stride"].update(
@@ -144,9 +149,9 @@ class Derived:
         self.max_points = int(vg["max_number_of_points_per_voxel"])
         self.max_voxels = int(vg["max_number_of_voxels"])
         self.num_point_features = int(s["num_point_features"])
-        if bool(s["voxel_feature_extractor"].get("with_distance", False)):
-            raise NotImplementedError("with_distance=True is unused in the reference config and not built")
-        self.pfn_in = self.num_point_features + 5
+        # model/pointpillars.py:185-188: one more PFN input feature (the point's Euclidean norm)
+        self.with_distance = bool(s["voxel_feature_extractor"].get("with_distance", False))
+        self.pfn_in = self.num_point_features + 5 + (1 if self.with_distance else 0)
         self.pfn_filters = int(s["voxel_feature_extractor"]["num_filters"])
         r = s["rpn"]
         self.layer_nums = [int(v) for v in r["layer_nums"]]
@@ -175,12 +180,18 @@ class Derived:
         n_sizes = int(np.array(ag["sizes"]).reshape([-1, 3]).shape[0])
         self.num_anchor_per_loc = len(ag["rotations"]) * n_sizes
         self.num_class = int(s["num_class"])
-        if self.num_class != 1 or not s["encode_background_as_zeros"] or s["use_multi_class_nms"]:
+        if not s["encode_background_as_zeros"] or s["use_multi_class_nms"]:
             raise NotImplementedError(
-                "only num_class=1 / encode_background_as_zeros / single-class NMS is implemented "
-                "in the reference's predict() (model/voxelnet.py:1152-1185 are TF stubs)")
-        if not s["use_direction_classifier"]:
-            raise NotImplementedError("use_direction_classifier=False is not built")
+                "only encode_background_as_zeros / single-pass NMS is implemented "
+                "in the reference's predict() (model/voxelnet.py:1152-1157, :1167 are TF stubs)")
+        # model/voxelnet.py:690,714,1093,1297: without it the RPN has no conv_dir_cls and predict() does not flip
+        self.use_direction_classifier = bool(s["use_direction_classifier"])
+        # num_class > 1 is a TF stub in the reference's predict() (model/voxelnet.py:1183-1185: reduce_max /
+        # argmax over the class scores of an anchor); built here as that documented extension.  The fused head
+        # row holds 32 columns.
+        cols = self.num_anchor_per_loc * (7 + self.num_class + (2 if self.use_direction_classifier else 0))
+        if self.num_class < 1 or cols > 32:
+            raise NotImplementedError(f"num_anchor_per_loc * (7 + num_class + 2) = {cols} head columns > 32")
         self.num_anchors = self.head_h * self.head_w * self.num_anchor_per_loc
         self.nms_pre_max_size = int(s["nms_pre_max_size"])
         self.nms_post_max_size = int(s["nms_post_max_size"])
@@ -198,8 +209,9 @@ class Derived:
 
     def model_dict(self):
         return {"voxel_size": self.voxel_size, "pc_range": self.pc_range, "grid": self.grid,
-                "rpn": self.rpn_dict()}
+                "rpn": self.rpn_dict(), "with_distance": self.with_distance}
 
     def nms_dict(self):
         return {"nms_score_threshold": self.nms_score_threshold, "nms_pre_max_size": self.nms_pre_max_size,
-                "nms_post_max_size": self.nms_post_max_size, "nms_iou_threshold": self.nms_iou_threshold}
+                "nms_post_max_size": self.nms_post_max_size, "nms_iou_threshold": self.nms_iou_threshold,
+                "num_class": self.num_class, "use_direction_classifier": self.use_direction_classifier}

@@ -72,8 +72,8 @@ void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, c
                         float threshold, int* integ, uint8_t* mask, hipStream_t s) {
     if (batch <= 0) return;
     const int rows = batch * ny;
-    hipLaunchKernelGGL(k_occ_rowscan, dim3((rows + 3) / 4), dim3(256), 0, s, cellmap, rows, nz, ny, nx, integ);
-    hipLaunchKernelGGL(k_colscan, dim3((batch * nx + 255) / 256), dim3(256), 0, s, integ, batch, ny, nx);
-    hipLaunchKernelGGL(k_anchor_lookup, dim3((unsigned)((A + 255) / 256), batch), dim3(256), 0, s, integ, cells, A,
+    PP_LAUNCH("k_occ_rowscan", k_occ_rowscan, dim3((rows + 3) / 4), dim3(256), 0, s, cellmap, rows, nz, ny, nx, integ);
+    PP_LAUNCH("k_colscan", k_colscan, dim3((batch * nx + 255) / 256), dim3(256), 0, s, integ, batch, ny, nx);
+    PP_LAUNCH("k_anchor_lookup", k_anchor_lookup, dim3((unsigned)((A + 255) / 256), batch), dim3(256), 0, s, integ, cells, A,
                        ny, nx, threshold, mask);
 }

@@ -30,7 +30,30 @@
 #include "pp_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Split-precision operand pieces (PP_SPLIT_MODE, a build-time choice; pp_api.hip splits the weights the same way):
+//   0: three bfloat16 pieces per float32 value, six products (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid)
+//   1: two float16 pieces (11 significand bits each), three products (hi*hi, hi*mid, mid*hi): the dropped
+//      mid*mid term and the two-piece representation are each ~2^-22 relative
+//   2: two float16 pieces, four products (+ mid*mid)
+#if PP_SPLIT_MODE == 0
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define PC_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#else
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));   // (name kept: "one 8-element piece operand")
+#define PC_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+#endif
+// ACC += X * Y with X the first MFMA operand; smallest terms first
+#if PP_SPLIT_MODE == 0
+#define PC_PRODUCTS(ACC, XH, XM, XL, YH, YM, YL) \
+    ACC = PC_MFMA(XL, YH, ACC); ACC = PC_MFMA(XH, YL, ACC); ACC = PC_MFMA(XM, YM, ACC); \
+    ACC = PC_MFMA(XM, YH, ACC); ACC = PC_MFMA(XH, YM, ACC); ACC = PC_MFMA(XH, YH, ACC);
+#elif PP_SPLIT_MODE == 1
+#define PC_PRODUCTS(ACC, XH, XM, XL, YH, YM, YL) \
+    ACC = PC_MFMA(XM, YH, ACC); ACC = PC_MFMA(XH, YM, ACC); ACC = PC_MFMA(XH, YH, ACC);
+#else
+#define PC_PRODUCTS(ACC, XH, XM, XL, YH, YM, YL) \
+    ACC = PC_MFMA(XM, YM, ACC); ACC = PC_MFMA(XM, YH, ACC); ACC = PC_MFMA(XH, YM, ACC); ACC = PC_MFMA(XH, YH, ACC);
+#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // 16-byte buffer load: address = SRD base + voffset (VGPR, bytes) + soffset (SGPR, bytes).  One VGPR
@@ -87,6 +110,11 @@ struct GemmArgs {
     int k, cout;          // deconv
     const int* occ;       // sparse input (k_sep_u<..., OCC = 1> / k_sep_k4): cell -> pillar map, see LayerDesc::d_occ
     int occ_nz;
+    // last fused-head branch only: the finished class logits of every pixel also go to a compact plane
+    // [pixels][cls_ncol] (head columns cls_col0 .. cls_col0 + cls_ncol), which is all the post-process reads
+    // of the head map for its candidate scan (8 bytes per pixel instead of a 128-byte row); NULL: not written
+    float* cls_plane;
+    int cls_col0, cls_ncol;
 };
 
 // D[row][col] of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -670,6 +698,7 @@ __device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2,
 // on the bf16 matrix pipe with float32 accumulation: float32-equivalent accuracy (the dropped terms
 // are < 2^-24 relative) at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 16 channels.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#if PP_SPLIT_MODE == 0
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
     // two values at a time: one v_cvt_pk_bf16_f32 per pair and piece; the bf16 -> f32 widening is a shift / a mask
@@ -689,6 +718,24 @@ __device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8& hi, bf
         lo[j] = l.x; lo[j + 1] = l.y;
     }
 }
+#else
+// two float16 pieces: hi = rne(v), mid = rne(v - hi) (the subtraction is exact).  |v| must stay below 65504
+// (BN-folded weights and BN-normalised activations are O(1)..O(100)); below ~0.1 the mid piece is a float16
+// subnormal, i.e. the pair carries an ABSOLUTE error of at most 2^-25 instead of 2^-22 relative.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f32x2_t x = {v[j], v[j + 1]};
+        const f16x2_t h = __builtin_convertvector(x, f16x2_t);
+        const f32x2_t r1 = {v[j] - (float)h.x, v[j + 1] - (float)h.y};
+        const f16x2_t m = __builtin_convertvector(r1, f16x2_t);
+        hi[j] = h.x; hi[j + 1] = h.y;
+        mid[j] = m.x; mid[j + 1] = m.y;
+    }
+    lo = mid;   // unused by the two-piece product sets
+}
+#endif
 
 // n / d and n % d for 0 <= n < 2^24 (exact in float32) with a precomputed reciprocal: a multiply, a
 // truncation and one correction step each way instead of the ~40-instruction integer division
@@ -725,8 +772,8 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     constexpr int SAW = 32 * LSTR;                   // one wave-private A buffer (floats)
     // weight tile in LDS: PREC 0 [NT][16 + 4] floats; PREC 1 [3 pieces][NT][16 bf16 = 8 floats], the two
     // 16-byte halves of a row swapped on odd groups of 8 rows (conflict-free ds_read_b128 without padding)
-    constexpr int SB = (PREC == 0) ? NT * LSTR : 3 * NT * 8;
-    constexpr int NB4 = (PREC == 0) ? (NT * G + 255) / 256 : (NT * 6 + 255) / 256;   // 16-byte weight items per thread per chunk
+    constexpr int SB = (PREC == 0) ? NT * LSTR : PP_NPIECE * NT * 8;
+    constexpr int NB4 = (PREC == 0) ? (NT * G + 255) / 256 : (NT * 2 * PP_NPIECE + 255) / 256;   // 16-byte weight items per thread per chunk
     constexpr int NTILES = NT / 32;
     constexpr int KQ = KCH / 8;
     __shared__ __attribute__((aligned(16))) float smem[8 * SAW + 2 * SB + 9 * 256];
@@ -812,7 +859,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         }                                                                                                \
     }
     // weight staging items (16 bytes each): global byte offset and LDS float offset, fixed for the K loop
-    constexpr int NBI = (PREC == 0) ? NT * G : NT * 6;   // items per chunk
+    constexpr int NBI = (PREC == 0) ? NT * G : NT * 2 * PP_NPIECE;   // items per chunk
     unsigned boff[NB4];
     int bdst[NB4];
 #pragma unroll
@@ -827,7 +874,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
             bdst[r] = piece * (NT * 8) + row * 8 + ((half ^ ((row >> 3) & 1)) * 4);
         }
     }
-    const unsigned bstep = (PREC == 0) ? (unsigned)(KCH * 4) : (unsigned)(3 * a.n_total * 32);   // bytes per K-chunk
+    const unsigned bstep = (PREC == 0) ? (unsigned)(KCH * 4) : (unsigned)(PP_NPIECE * a.n_total * 32);   // bytes per K-chunk
     float4 rin[NLD];
     float4 rb0, rb1, rb2;
     rb0 = rb1 = rb2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -895,12 +942,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);                         \
             const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);                \
             const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);            \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);                   \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);                   \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);                   \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);                   \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);                   \
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);                   \
+            PC_PRODUCTS(acc[n], ah, am, al, bh, bm, bl)                                                  \
         }                                                                                                \
     }                                                                                                    \
     if (!(dbg & 1) && PREC == 0) {                                                                       \
@@ -1057,11 +1099,11 @@ static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
     gx = (gx + 7) & ~7;
     dim3 grid((unsigned)gx, ny);
     if (bf && a.occ != nullptr)
-        hipLaunchKernelGGL((k_sep_u<NT, S, WPB, 1, 1>), grid, dim3(256), 0, s, a, ntiles);
+        PP_LAUNCH("k_sep_u", (k_sep_u<NT, S, WPB, 1, 1>), grid, dim3(256), 0, s, a, ntiles);
     else if (bf)
-        hipLaunchKernelGGL((k_sep_u<NT, S, WPB, 1>), grid, dim3(256), 0, s, a, ntiles);
+        PP_LAUNCH("k_sep_u", (k_sep_u<NT, S, WPB, 1>), grid, dim3(256), 0, s, a, ntiles);
     else
-        hipLaunchKernelGGL((k_sep_u<NT, S, WPS, 0>), grid, dim3(256), 0, s, a, ntiles);
+        PP_LAUNCH("k_sep_u", (k_sep_u<NT, S, WPS, 0>), grid, dim3(256), 0, s, a, ntiles);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1079,9 +1121,9 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
     constexpr int KCH = 16, LSTR = KCH + 4;
     constexpr int WW = S + 3, NLD = 3 * WW;
     constexpr int SAW = 32 * LSTR;              // one A buffer (floats)
-    constexpr int SB = 3 * NT * 8;              // one weight buffer: [3 pieces][NT][16 bf16]
+    constexpr int SB = PP_NPIECE * NT * 8;              // one weight buffer: [3 pieces][NT][16 bf16]
     constexpr int NTILES = NT / 32;
-    constexpr int NBL = NT * 6 / 64;            // 16-byte weight items per lane per chunk
+    constexpr int NBL = NT * 2 * PP_NPIECE / 64;            // 16-byte weight items per lane per chunk
     constexpr int WV = 2 * SAW + 2 * SB;        // floats per wave
     static_assert(4 * NTILES * 16 * 64 <= 4 * WV, "reduction scratch overlays the staging tiles");
     __shared__ __attribute__((aligned(16))) float smem[4 * WV + 9 * 256];
@@ -1130,7 +1172,7 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
         boff[r] = (unsigned)(((piece * a.n_total + n0 + row) * 16 + half * 8) * 2);
         bdst[r] = piece * (NT * 8) + row * 8 + ((half ^ ((row >> 3) & 1)) * 4);
     }
-    const unsigned bstep = (unsigned)(3 * a.n_total * 32);   // bytes per K-chunk of the split weights
+    const unsigned bstep = (unsigned)(PP_NPIECE * a.n_total * 32);   // bytes per K-chunk of the split weights
     float4 rin[NLD];
     float4 rb[NBL];
 #define K4_LOAD(KC)                                                                                      \
@@ -1193,12 +1235,7 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);
                 const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+                PC_PRODUCTS(acc[n], ah, am, al, bh, bm, bl)
             }
         }
         if (j + 1 < niter) {
@@ -1253,7 +1290,7 @@ static bool sep_k4_runs(const void* wt16, int cin, int n_total, long long M, int
 template <int S>
 static void launch_k4(const GemmArgs& a, int n_total, hipStream_t s) {
     dim3 grid((unsigned)((a.M + 31) / 32), n_total / 64);
-    hipLaunchKernelGGL((k_sep_k4<64, S>), grid, dim3(256), 0, s, a);
+    PP_LAUNCH("k_sep_k4", (k_sep_k4<64, S>), grid, dim3(256), 0, s, a);
 }
 
 // Epilogue of one 128-pixel deconv tile (see k_deconv_u).  Accumulator layout (operands swapped in the
@@ -1301,16 +1338,11 @@ __device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (
                                      v[8 * g + 4], v[8 * g + 5], v[8 * g + 6], v[8 * g + 7]};
                 bf16x8 xh, xm, xl;
                 split_bf16x3(av, xh, xm, xl);
-                const float* hW = sHW + ((n * 2 + g) * 3 * 32 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+                const float* hW = sHW + ((n * 2 + g) * PP_NPIECE * 32 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
                 const bf16x8 wh = *reinterpret_cast<const bf16x8*>(hW);
                 const bf16x8 wm = *reinterpret_cast<const bf16x8*>(hW + 32 * 8);
                 const bf16x8 wl = *reinterpret_cast<const bf16x8*>(hW + 2 * 32 * 8);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, hacc, 0, 0, 0);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, hacc, 0, 0, 0);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, hacc, 0, 0, 0);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, hacc, 0, 0, 0);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, hacc, 0, 0, 0);
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, hacc, 0, 0, 0);
+                PC_PRODUCTS(hacc, wh, wm, wl, xh, xm, xl)
             }
         }
         if (dst != nullptr && ok) {   // concat slice (only when the heads are not fused): 4 consecutive channels per store
@@ -1323,6 +1355,14 @@ __device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(hrow + 8 * g) = make_float4(hacc[4 * g], hacc[4 * g + 1], hacc[4 * g + 2], hacc[4 * g + 3]);
+        if (a.cls_plane != nullptr) {   // register r of this lane is head column 8*(r/4) + 4h + r%4
+            float* cp = a.cls_plane + orow * a.cls_ncol;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = 8 * (r >> 2) + 4 * h + (r & 3) - a.cls_col0;
+                if ((unsigned)col < (unsigned)a.cls_ncol) cp[col] = hacc[r];
+            }
+        }
     }
 }
 
@@ -1348,10 +1388,10 @@ template <int NT, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
     constexpr int KCH = 16;
     constexpr int NTILES = NT / 32;
-    constexpr int SB = 3 * NT * 8;                       // one weight buffer: [3 pieces][NT][8 floats]
-    constexpr int NBI = NT * 6;                          // 16-byte weight items per chunk
+    constexpr int SB = PP_NPIECE * NT * 8;                       // one weight buffer: [3 pieces][NT][8 floats]
+    constexpr int NBI = NT * 2 * PP_NPIECE;                          // 16-byte weight items per chunk
     constexpr int NB4 = (NBI + 255) / 256;
-    constexpr int SHW = (NT / 16) * 3 * 32 * 8;          // head weights: [NT/16][3][32 cols][8 floats]
+    constexpr int SHW = (NT / 16) * PP_NPIECE * 32 * 8;          // head weights: [NT/16][3][32 cols][8 floats]
     __shared__ __attribute__((aligned(16))) float sB[2 * SB];
     __shared__ __attribute__((aligned(16))) float sHW[SHW];
     __shared__ float s_bias[NT];
@@ -1397,7 +1437,7 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
         boff[r] = (unsigned)(((piece * a.n_total + n0 + row) * 16 + half * 8) * 2);
         bdst[r] = piece * (NT * 8) + row * 8 + ((half ^ ((row >> 3) & 1)) * 4);
     }
-    const unsigned bstep = (unsigned)(3 * a.n_total * 32);
+    const unsigned bstep = (unsigned)(PP_NPIECE * a.n_total * 32);
     float4 rb0, rb1, rb2;
     rb0 = rb1 = rb2 = make_float4(0.f, 0.f, 0.f, 0.f);
     static_assert(NB4 <= 3, "weight prefetch registers");
@@ -1471,12 +1511,7 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
                 const bf16x8 bh_ = *reinterpret_cast<const bf16x8*>(cB_ + n * 32 * 8);                   \
                 const bf16x8 bm_ = *reinterpret_cast<const bf16x8*>(cB_ + NT * 8 + n * 32 * 8);          \
                 const bf16x8 bl_ = *reinterpret_cast<const bf16x8*>(cB_ + 2 * NT * 8 + n * 32 * 8);      \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_, al_, acc[n], 0, 0, 0);             \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl_, ah_, acc[n], 0, 0, 0);             \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm_, am_, acc[n], 0, 0, 0);             \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_, am_, acc[n], 0, 0, 0);             \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm_, ah_, acc[n], 0, 0, 0);             \
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh_, ah_, acc[n], 0, 0, 0);             \
+                PC_PRODUCTS(acc[n], bh_, bm_, bl_, ah_, am_, al_)                                        \
             }                                                                                            \
         }                                                                                                \
         if (i_ + 1 < total) D_STORE_B((i_ + 1) & 1)   /* weight tile of position i+1 -> LDS */          \
@@ -1519,13 +1554,14 @@ template <int NT>
 __global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
     constexpr int KCH = 16;
     constexpr int NTILES = NT / 32;
-    constexpr int SB = 3 * NT * 8;                       // one weight tile: [3 pieces][NT][8 floats]
-    constexpr int NBL = NT * 6 / 64;                     // 16-byte weight items per lane per chunk
-    constexpr int SHW = (NT / 16) * 3 * 32 * 8;
+    constexpr int SB = PP_NPIECE * NT * 8;                       // one weight tile: [3 pieces][NT][8 floats]
+    constexpr int NBL = NT * 2 * PP_NPIECE / 64;                     // 16-byte weight items per lane per chunk
+    constexpr int SHW = (NT / 16) * PP_NPIECE * 32 * 8;
     constexpr int SLOT = 16 * 64;                        // one partial accumulator tile (floats)
     constexpr int OWNERS = NTILES < 4 ? NTILES : 4;
-    static_assert((4 * NTILES - OWNERS) * SLOT <= 4 * SB, "partial sums overlay the weight tiles");
-    __shared__ __attribute__((aligned(16))) float sR[4 * SB];
+    // the partial sums overlay the weight tiles (and need more room than two-piece weight tiles give)
+    constexpr int SR = (4 * SB > (4 * NTILES - OWNERS) * SLOT) ? 4 * SB : (4 * NTILES - OWNERS) * SLOT;
+    __shared__ __attribute__((aligned(16))) float sR[SR];
     __shared__ __attribute__((aligned(16))) float sHW[SHW];
     __shared__ float s_bias[NT];
     __shared__ float s_hbias[PP_HEAD_COLS];
@@ -1565,7 +1601,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
         boff[r] = (unsigned)(((piece * a.n_total + n0 + row) * 16 + half * 8) * 2);
         bdst[r] = piece * (NT * 8) + row * 8 + ((half ^ ((row >> 3) & 1)) * 4);
     }
-    const unsigned bstep = (unsigned)(3 * a.n_total * 32);
+    const unsigned bstep = (unsigned)(PP_NPIECE * a.n_total * 32);
     float4 rb[NBL];
 #pragma unroll
     for (int r = 0; r < NBL; ++r) rb[r] = buf_load16(rs_wt, boff[r], (unsigned)wave * bstep);
@@ -1601,12 +1637,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);
                 const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm, am, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, am, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm, ah, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[n], 0, 0, 0);
+                PC_PRODUCTS(acc[n], bh, bm, bl, ah, am, al)
             }
         }
     }
@@ -1668,16 +1699,11 @@ __global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
                                      v[8 * g + 4], v[8 * g + 5], v[8 * g + 6], v[8 * g + 7]};
                 bf16x8 xh, xm, xl;
                 split_bf16x3(av, xh, xm, xl);
-                const float* hW = sHW + ((wave * 2 + g) * 3 * 32 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+                const float* hW = sHW + ((wave * 2 + g) * PP_NPIECE * 32 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
                 const bf16x8 wh = *reinterpret_cast<const bf16x8*>(hW);
                 const bf16x8 wm = *reinterpret_cast<const bf16x8*>(hW + 32 * 8);
                 const bf16x8 wl = *reinterpret_cast<const bf16x8*>(hW + 2 * 32 * 8);
-                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, hpart, 0, 0, 0);
-                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, hpart, 0, 0, 0);
-                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, hpart, 0, 0, 0);
-                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, hpart, 0, 0, 0);
-                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, hpart, 0, 0, 0);
-                hpart = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, hpart, 0, 0, 0);
+                PC_PRODUCTS(hpart, wh, wm, wl, xh, xm, xl)
             }
         }
     }
@@ -1718,6 +1744,14 @@ __global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(hrow + 8 * g) = make_float4(hv[4 * g], hv[4 * g + 1], hv[4 * g + 2], hv[4 * g + 3]);
+        if (a.cls_plane != nullptr) {   // compact class-logit plane (see GemmArgs::cls_plane)
+            float* cp = a.cls_plane + orow * a.cls_ncol;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = 8 * (r >> 2) + 4 * h + (r & 3) - a.cls_col0;
+                if ((unsigned)col < (unsigned)a.cls_ncol) cp[col] = hv[r];
+            }
+        }
     }
 }
 
@@ -1735,7 +1769,7 @@ static bool deconv_k4_runs(const LayerDesc& L, long long M, int ablate) {
 template <int NT>
 static void launch_deconv_k4(const GemmArgs& a, int n_total, hipStream_t s) {
     dim3 grid((unsigned)((a.M + 31) / 32), n_total / NT);
-    hipLaunchKernelGGL((k_deconv_k4<NT>), grid, dim3(256), 0, s, a);
+    PP_LAUNCH("k_deconv_k4", (k_deconv_k4<NT>), grid, dim3(256), 0, s, a);
 }
 
 template <int NT>
@@ -1748,14 +1782,14 @@ static void launch_deconv_u(const GemmArgs& a, int n_total, hipStream_t s) {
     int gx = ntiles < slots ? ntiles : slots;
     gx = (gx + 7) & ~7;
     dim3 grid((unsigned)gx, ny);
-    hipLaunchKernelGGL((k_deconv_u<NT, WPS>), grid, dim3(256), 0, s, a, ntiles);
+    PP_LAUNCH("k_deconv_u", (k_deconv_u<NT, WPS>), grid, dim3(256), 0, s, a, ntiles);
 }
 
 template <int NT, int MODE>
 static void launch_t(const GemmArgs& a, int n_total, hipStream_t s) {
     const unsigned mt = (unsigned)((a.M + PX_TILE - 1) / PX_TILE);
     dim3 grid(mt, n_total / NT);
-    hipLaunchKernelGGL((k_gemm_layer<NT, MODE>), grid, dim3(256), 0, s, a);
+    PP_LAUNCH("k_gemm_layer", (k_gemm_layer<NT, MODE>), grid, dim3(256), 0, s, a);
 }
 
 // 128-pixel tiles (8-wave workgroups: every SIMD hosts one consumer and one producer wave) are the
@@ -1771,10 +1805,10 @@ template <int NT, int MODE, int S>
 static void launch_ws(const GemmArgs& a, int n_total, hipStream_t s) {
     if (ws_small_tile(a.M, n_total, NT)) {
         dim3 grid((unsigned)((a.M + 63) / 64), n_total / NT);
-        hipLaunchKernelGGL((k_gemm_ws<NT, MODE, S, 64>), grid, dim3(256), 0, s, a);
+        PP_LAUNCH("k_gemm_ws", (k_gemm_ws<NT, MODE, S, 64>), grid, dim3(256), 0, s, a);
     } else {
         dim3 grid((unsigned)((a.M + 127) / 128), n_total / NT);
-        hipLaunchKernelGGL((k_gemm_ws<NT, MODE, S, 128>), grid, dim3(512), 0, s, a);
+        PP_LAUNCH("k_gemm_ws", (k_gemm_ws<NT, MODE, S, 128>), grid, dim3(512), 0, s, a);
     }
 }
 
@@ -1810,6 +1844,11 @@ static int sep_u_nt(const LayerDesc& L, int batch) {
 }
 
 long long* g_stamps = nullptr;   // tuning aid: device buffer for in-kernel stamps (pp_bench_layer, ablate & 64)
+
+// workgroups per CU of the split-precision k_sep_u<128, 1, ...> instantiation (its register budget: 256 / 168)
+#ifndef PP_SEP128_WPB
+#define PP_SEP128_WPB 2
+#endif
 
 // which kernel runs layer L (shared by the launcher and the profiler tags)
 static bool use_ws(const LayerDesc& L) {
@@ -1857,7 +1896,7 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
         const int unt = sep_u_nt(L, batch);
         const bool bf = L.d_wt16 != nullptr && split_precision(0);
         int wps;   // workgroups per CU of the instantiation launch_layer picks (launch_u<NT, S, WPS, WPB>)
-        if (L.stride == 1) wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 3 : 4);
+        if (L.stride == 1) wps = bf ? (unt == 128 ? PP_SEP128_WPB : 3) : (unt == 128 ? 3 : 4);
         else wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 2 : (unt == 64 ? 3 : 4));
         snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d,%d,%d>", unt, L.stride, wps, bf ? 1 : 0, (bf && L.d_occ) ? 1 : 0);
     } else if (deconv_uniform(L, 0) && deconv_k4_runs(L, layer_rows(L, batch), 0)) {
@@ -1871,6 +1910,12 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
         snprintf(buf, sizeof(buf), "k_gemm_layer<%d,%d>", nt, mode);
     }
     return std::string(buf);
+}
+
+// does layer L (the last fused-head deconv) leave the compact class-logit plane?  (the uniform-wave and
+// split-K deconv kernels do; the fallback generations do not and the post-process then scans the head rows)
+bool layer_writes_cls_plane(const LayerDesc& L) {
+    return L.kind == LAYER_DECONV && L.head_mode == 2 && L.d_cls_plane != nullptr && deconv_uniform(L, 0);
 }
 
 int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, int ablate) {
@@ -1892,6 +1937,8 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
     a.stride = L.stride; a.ld_out = L.ld_out; a.co_off = L.co_off;
     a.k = L.k; a.cout = L.cout;
     a.occ = L.d_occ; a.occ_nz = L.occ_nz;
+    a.cls_plane = layer_writes_cls_plane(L) ? L.d_cls_plane : nullptr;
+    a.cls_col0 = L.cls_col0; a.cls_ncol = L.cls_ncol;
     if (L.kind == LAYER_SEP) {
         a.px_h = L.out_h; a.px_w = L.out_w; a.epi = 0;
         a.M = batch * L.out_h * L.out_w;
@@ -1905,7 +1952,7 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
                 if (L.stride == 1) launch_k4<1>(a, L.n_total, s);
                 else launch_k4<2>(a, L.n_total, s);
             } else if (L.stride == 1) {
-                if (nt == 128) launch_u<128, 1, 3, 2>(a, L.n_total, s);
+                if (nt == 128) launch_u<128, 1, 3, PP_SEP128_WPB>(a, L.n_total, s);
                 else if (nt == 64) launch_u<64, 1, 4, 3>(a, L.n_total, s);
                 else launch_u<32, 1, 4, 3>(a, L.n_total, s);
             } else {

@@ -48,9 +48,11 @@ __device__ __forceinline__ float wave_sum(float x) {
 // cells per wavefront: pillars hold 1..T points, so a tile's cost varies by 100x; small tiles keep
 // the heaviest wave short (the kernel ends with its slowest wave)
 #define PFN_CW 4
-template <int CPL, int F, bool PADDED>
+// DIST: voxel_feature_extractor.with_distance (model/pointpillars.py:185-188): a ninth / tenth input feature,
+// the Euclidean norm of the point's raw xyz (tf.norm, float32), after the cluster and centre offsets
+template <int CPL, int F, bool PADDED, bool DIST = false>
 __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
-    constexpr int FA = F + 5;
+    constexpr int FA = F + 5 + (DIST ? 1 : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int ncanvas = p.ny * p.nx;
@@ -117,8 +119,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
             const int pid = __builtin_amdgcn_readfirstlane(map[(size_t)z * ncanvas + cell]);
             if (pid < 0) continue;
             int n, nsum;
-            const float* src;           // PADDED: rows of this pillar
-            const unsigned* sidx = nullptr;
+            const float* src;           // rows of this pillar (padded tensor, or its run of the pillar-sorted points)
             if (PADDED) {
                 n = __builtin_amdgcn_readfirstlane(min(max(p.num_points[pid], 0), T));
                 nsum = T;               // the reference sums all T rows (model/pointpillars.py:143)
@@ -127,15 +128,14 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
                 const int start = __builtin_amdgcn_readfirstlane(ps[pid]);
                 n = __builtin_amdgcn_readfirstlane(min(ps[pid + 1] - start, T));
                 nsum = n;
-                sidx = p.sorted_idx + n0 + start;
-                src = p.pts + (size_t)n0 * F;
+                src = p.pts_sorted + (size_t)(n0 + start) * F;
             }
             // ---- mean over the pillar ----
             float sx = 0.f, sy = 0.f, sz = 0.f;
             for (int j0 = 0; j0 < nsum; j0 += 64) {
                 const int j = j0 + lane;
                 if (j < nsum) {
-                    const float* q = PADDED ? (src + (size_t)j * F) : (src + (size_t)sidx[j] * F);
+                    const float* q = src + (size_t)j * F;
                     sx += q[0]; sy += q[1]; sz += q[2];
                 }
             }
@@ -163,10 +163,12 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
 #pragma unroll
                 for (int f = 0; f < F; ++f) pt[f] = 0.f;
                 if (j < n) {
-                    const float* q = PADDED ? (src + (size_t)j * F) : (src + (size_t)sidx[j] * F);
+                    const float* q = src + (size_t)j * F;
 #pragma unroll
                     for (int f = 0; f < F; ++f) pt[f] = q[f];
                 }
+                float pdist = 0.f;
+                if (DIST) pdist = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(pt[0], pt[0]), __fmul_rn(pt[1], pt[1])), __fmul_rn(pt[2], pt[2])));
                 pt[0] = pt[0] - cxf;   // pillar-local coordinates (the reference's f_center features)
                 pt[1] = pt[1] - cyf;
                 const int cnt = min(64, n - j0);
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
                     float ft[F];
 #pragma unroll
                     for (int f = 0; f < F; ++f) ft[f] = bcast(pt[f], jj);
+                    const float fd = DIST ? bcast(pdist, jj) : 0.f;
 #pragma unroll
                     for (int q = 0; q < CPL; ++q) {
                         float o = kp[q];
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
                         o = fmaf(ft[1], wsy[q], o);
                         o = fmaf(ft[2], wsz[q], o);
                         if (F > 3) o = fmaf(ft[F - 1], w[F - 1][q], o);
+                        if (DIST) o = fmaf(fd, w[FA - 1][q], o);
                         m[q] = fmaxf(m[q], o);
                     }
                 }
@@ -296,8 +300,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     const int excl = incl - cnt;
     const int tot = __builtin_amdgcn_readlane(incl, 63);
     if (p.sparse && tot == 0) return;                 // sparse canvas: nothing to write for cells without pillars
-    const unsigned* sidx = p.sorted_idx + n0;
-    const float* src = p.pts + (size_t)n0 * F;
+    const float* src = p.pts_sorted + (size_t)n0 * F;   // this frame's pillar-sorted points: a slot is one contiguous run
 
     // one batch = stream positions base..base+63, one per lane: slot, coordinates
     struct Batch { int slot; float x, y, z, i; };
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
         const float pcx = __shfl(slot_cx, sl), pcy = __shfl(slot_cy, sl);
         if (g < tot) {
             r.slot = sl;
-            const float* q = src + (size_t)sidx[st + (g - ex)] * F;
+            const float* q = src + (size_t)(st + (g - ex)) * F;
             r.x = q[0] - pcx;      // pillar-local coordinates (the reference's f_center features), one
             r.y = q[1] - pcy;      // subtraction per point instead of one per point and lane
             r.z = q[2];
@@ -442,13 +445,16 @@ template <int CPL, int F>
 static void launch_pfn_t(const PfnParams& p, bool padded, hipStream_t s) {
     const int ncanvas = p.ny * p.nx;
     dim3 grid((ncanvas + 4 * PFN_CW - 1) / (4 * PFN_CW), p.batch);
-    if (padded) {
-        hipLaunchKernelGGL((k_pfn_canvas<CPL, F, true>), grid, dim3(256), 0, s, p);
+    if (p.with_distance) {   // the generic kernel carries the distance feature (not a shipped configuration)
+        if (padded) PP_LAUNCH("k_pfn_canvas", (k_pfn_canvas<CPL, F, true, true>), grid, dim3(256), 0, s, p);
+        else PP_LAUNCH("k_pfn_canvas", (k_pfn_canvas<CPL, F, false, true>), grid, dim3(256), 0, s, p);
+    } else if (padded) {
+        PP_LAUNCH("k_pfn_canvas", (k_pfn_canvas<CPL, F, true>), grid, dim3(256), 0, s, p);
     } else if (PFN2_CW * p.nz <= 64 && !pfn_first_generation()) {
         dim3 grid2((ncanvas + 4 * PFN2_CW - 1) / (4 * PFN2_CW), p.batch);
-        hipLaunchKernelGGL((k_pfn_canvas2<CPL, F>), grid2, dim3(256), 0, s, p);
+        PP_LAUNCH("k_pfn_canvas2", (k_pfn_canvas2<CPL, F>), grid2, dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL((k_pfn_canvas<CPL, F, false>), grid, dim3(256), 0, s, p);
+        PP_LAUNCH("k_pfn_canvas", (k_pfn_canvas<CPL, F, false>), grid, dim3(256), 0, s, p);
     }
 }
 

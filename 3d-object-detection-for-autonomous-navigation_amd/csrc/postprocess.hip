@@ -45,6 +45,7 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     __shared__ float s_aabb[KMAX][4];
     __shared__ float s_score[KMAX];
     __shared__ int s_dir[KMAX];
+    __shared__ int s_label[KMAX];
     __shared__ int s_anchor[KMAX];
     __shared__ unsigned long long s_mask[KMAX][2];
     __shared__ int s_keep[KMAX];
@@ -61,13 +62,25 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     P_STAMP()
     const long long A = p.A;
     const int napl = p.napl;
-    const int nb = napl * 7, nc = napl;
-    // fused head map row of pixel px: [box napl*7 | cls napl | dir napl*2 | pad]; anchor a = px*napl + r
+    const int ncls = p.ncls;
+    const int nb = napl * 7, nc = napl * ncls;
+    // fused head map row of pixel px: [box napl*7 | cls napl*ncls | dir napl*2 | pad]; anchor a = px*napl + r,
+    // class logit k of that anchor at column nb + r*ncls + k (the reference reshapes cls_preds to
+    // [B, -1, num_class], model/voxelnet.py:1090).  More than one class: the anchor's score is its largest
+    // class score and its label the argmax (model/voxelnet.py:1183-1185; sigmoid is monotone, so the
+    // selection runs on the largest logit)
     const float* head = p.head + (size_t)b * (A / napl) * PP_HEAD_COLS;
     const uint8_t* msk = p.mask + (size_t)b * A;
+    // candidate scan source: the compact class-logit plane the last deconv left (napl*ncls floats per pixel,
+    // consecutive anchors = consecutive words) or, without it, the cls columns of the 128-byte head rows
+    const float* cplane = (p.cls != nullptr) ? p.cls + (size_t)b * A * ncls : nullptr;
     auto cls_of = [&](long long a) -> float {
         const long long px = a / napl;
-        return head[px * PP_HEAD_COLS + nb + (int)(a - px * napl)];
+        const float* q = (cplane != nullptr) ? cplane + a * ncls
+                                             : head + px * PP_HEAD_COLS + nb + (int)(a - px * napl) * ncls;
+        float m = q[0];
+        for (int k = 1; k < ncls; ++k) m = fmaxf(m, q[k]);
+        return m;
     };
     const float thr = p.score_thr;
     const int KTOP = 100;  // model/voxelnet.py:1207 (hard-coded)
@@ -239,10 +252,16 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         zg = __fsub_rn(zg, __fdiv_rn(hg, 2.f));
         s_box[tid][0] = xg; s_box[tid][1] = yg; s_box[tid][2] = zg;
         s_box[tid][3] = wg; s_box[tid][4] = lg; s_box[tid][5] = hg; s_box[tid][6] = rg;
-        const float lgt = hrow[nb + ar];
+        float lgt = hrow[nb + ar * ncls];
+        int lab = 0;
+        for (int k = 1; k < ncls; ++k) {
+            const float v = hrow[nb + ar * ncls + k];
+            if (v > lgt) { lgt = v; lab = k; }   // argmax: first maximum
+        }
+        s_label[tid] = lab;
         s_score[tid] = 1.f / (1.f + expf(-lgt));
         const float* d = hrow + nb + nc + ar * 2;
-        s_dir[tid] = (d[1] > d[0]) ? 1 : 0;  // np.argmax: first maximum
+        s_dir[tid] = (p.use_dir && d[1] > d[0]) ? 1 : 0;  // np.argmax: first maximum
         s_anchor[tid] = (int)a;
         // corners (-,-),(-,+),(+,+),(+,-) * dims, rotate by [[c,-s],[s,c]], + centre; min/max
         const float sn = sinf(rg), cs = cosf(rg);
@@ -339,8 +358,9 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         const int i = s_keep[tid];
         pp_detection* o = p.dets + (size_t)b * p.post_max + tid;
         float r = s_box[i][6];
-        const bool opp = (r > 0.f) != (s_dir[i] == 1);
-        r = (float)((double)r + (opp ? 3.141592653589793 : 0.0));  // f32 += f64 (numpy in-place add)
+        // model/voxelnet.py:1297-1310: the flip exists only with use_direction_classifier
+        const bool opp = p.use_dir && ((r > 0.f) != (s_dir[i] == 1));
+        if (p.use_dir) r = (float)((double)r + (opp ? 3.141592653589793 : 0.0));  // f32 += f64 (numpy in-place add)
         const float* M = p.calib + (size_t)b * 16;
         const double x = s_box[i][0], y = s_box[i][1], z = s_box[i][2];
 #pragma unroll
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         for (int q = 0; q < 6; ++q) o->box3d_lidar[q] = s_box[i][q];
         o->box3d_lidar[6] = r;
         o->score = s_score[i];
-        o->label = 0;
+        o->label = s_label[i];
         o->dir_label = s_dir[i];
         o->anchor_index = s_anchor[i];
         o->reserved = 0;
@@ -373,5 +393,5 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
 
 void launch_postprocess(const PostParams& p, hipStream_t s) {
     if (p.batch <= 0) return;
-    hipLaunchKernelGGL(k_postprocess, dim3(p.batch), dim3(PT), 0, s, p);
+    PP_LAUNCH("k_postprocess", k_postprocess, dim3(p.batch), dim3(PT), 0, s, p);
 }

@@ -4,6 +4,7 @@
 // postprocess.hip.  Everything runs on one HIP stream owned by the handle.
 #include <math.h>
 #include <algorithm>
+#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,6 +22,8 @@ struct KTime { const char* name; int ev; };
 
 }  // namespace
 
+thread_local PpProf g_pp_prof = {nullptr, nullptr};
+
 struct pp_engine {
     pp_config cfg;
     int device = 0;
@@ -28,7 +31,8 @@ struct pp_engine {
     std::string err;
     VoxGeom geom;
     int nx = 0, ny = 0, nz = 0, ncell = 0;
-    int head_h = 0, head_w = 0, napl = 0;
+    int head_h = 0, head_w = 0, napl = 0, ncls = 1;
+    bool use_dir = true, with_dist = false;
     int64_t A = 0;
     int C = 0, F = 0, T = 0, FA = 0, CC = 0;
     int B = 0, NMAX = 0;
@@ -37,8 +41,20 @@ struct pp_engine {
     std::map<std::string, std::vector<int64_t>> hshape;
     bool weights_ready = false, anchors_ready = false;
     std::vector<void*> allocs;
+    std::vector<void*> wallocs;   // weight buffers: released and re-made by every pp_finalize_weights
 
+    // raw points and frame offsets are double-buffered: an upload fills the buffer the previous pass is NOT
+    // reading (pp_upload_points_async on the copy stream, so the copy of batch k+1 runs beside the kernels of
+    // batch k); d_points / d_offsets point at the buffer the next pp_detect_async consumes
+    float* d_points_buf[2] = {nullptr, nullptr};
+    int* d_offsets_buf[2] = {nullptr, nullptr};
+    int in_buf = 0;                       // index of d_points / d_offsets
+    hipStream_t copy_stream = nullptr;   // the device's shared upload stream (not owned by the handle)
+    hipEvent_t ev_up = nullptr;           // recorded on the copy stream behind an asynchronous upload
+    bool up_pending = false;              // the next pp_detect_async must wait for ev_up
+    hipEvent_t ev_read[2] = {nullptr, nullptr};   // recorded on the main stream behind the pass that read buffer i
     float* d_points = nullptr;
+    float* d_points_sorted = nullptr;   // pillar-sorted copy left by k_voxel_frame (what the PFN streams)
     int* d_offsets = nullptr;
     int* d_cell = nullptr;
     int* d_first = nullptr;
@@ -53,6 +69,8 @@ struct pp_engine {
     float* d_act[2] = {nullptr, nullptr};
     float* d_concat = nullptr;
     float* d_head = nullptr;      // fused head map [B][H'*W'][PP_HEAD_COLS]
+    float* d_cls = nullptr;       // compact class-logit plane [B][H'*W'][napl*ncls] (last fused-head deconv -> post-process)
+    bool cls_plane_live = false;  // the last forward pass wrote d_cls (fused path with the uniform deconv kernels)
     bool fuse_heads = false;      // heads computed in the deconv epilogues (no concat buffer, no head launch)
     bool sparse_canvas = false;   // PFN writes occupied cells only; layer 0 consults the cell map (pp_finalize_weights)
     int* d_loss_labels = nullptr;      // training-side buffers (pp_head_loss), allocated on first use
@@ -81,12 +99,20 @@ struct pp_engine {
     float* d_feat = nullptr;   size_t cap_feat = 0;
 
     int cur_batch = 0, cur_max_n = 0;
-    std::vector<int> h_offsets;
+    int results_batch = 0;        // frames of the last enqueued pp_detect_async (0: no results to fetch)
+    // frame offsets travel through a small pinned ring (a pageable source would be staged synchronously and a
+    // single pinned buffer could be rewritten while its copy is still queued); a slot is reused only after the
+    // event recorded behind its copy has passed
+    static constexpr int OFF_RING = 4;
+    int* h_off_ring = nullptr;    // pinned [OFF_RING][B + 1]
+    hipEvent_t off_ev[OFF_RING] = {nullptr, nullptr, nullptr, nullptr};
+    int off_slot = 0;
+    hipEvent_t ev_in = nullptr;   // orders the engine's stream behind a producer stream (pp_upload_points_device)
 
     int prof = 0;
     // pp_detect_async as one hipGraph launch (captured on first use per (batch, max points per frame))
-    struct GraphSlot { hipGraphExec_t exec = nullptr; int batch = -1, bucket = -1; unsigned long long used = 0; };
-    GraphSlot graphs[4];          // small LRU keyed by (batch, point-count bucket)
+    struct GraphSlot { hipGraphExec_t exec = nullptr; int batch = -1, bucket = -1, buf = -1; unsigned long long used = 0; };
+    GraphSlot graphs[8];          // small LRU keyed by (batch, point-count bucket, input buffer)
     unsigned long long graph_tick = 0;
     int graph_state = 0;          // 0: try, -1: capture failed once (use plain launches)
     std::vector<hipEvent_t> events;
@@ -96,6 +122,19 @@ struct pp_engine {
 };
 
 namespace {
+
+// process-wide upload stream of a device (created on first use, lives as long as the process)
+hipStream_t device_copy_stream(int device) {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    streams[device] = s;
+    return s;
+}
 
 int fail(pp_engine* e, int code, const char* fmt, ...) {
     char buf[512];
@@ -148,19 +187,43 @@ int prof_event(pp_engine* e) {
     return e->ev_used++;
 }
 
+// Stage scope: the kernel launches inside record their own start / stop events (PP_LAUNCH) under `name`
+// (NULL: under each launch site's kernel name); non-kernel work (a memset) is bracketed with plain event records.
+}  // namespace
+
+bool pp_prof_events(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+    pp_engine* e = g_pp_prof.e;
+    if (e == nullptr || e->prof <= 0) return false;
+    const int e0 = prof_event(e), e1 = prof_event(e);
+    if (e0 < 0 || e1 < 0) return false;
+    e->ktimes.push_back({g_pp_prof.tag ? g_pp_prof.tag : name, e0});
+    *start = e->events[e0];
+    *stop = e->events[e1];
+    return true;
+}
+
+namespace {
+
 struct ProfScope {
     pp_engine* e;
     int e1 = -1;
-    ProfScope(pp_engine* en, const char* name) : e(en) {
+    ProfScope(pp_engine* en, const char* name, bool bracket = false) : e(en) {
         if (e->prof <= 0) return;
-        int e0 = prof_event(e);
-        e1 = prof_event(e);
-        if (e0 < 0 || e1 < 0) { e1 = -1; return; }
-        (void)hipEventRecord(e->events[e0], e->stream);
-        e->ktimes.push_back({name, e0});
+        if (bracket) {
+            int e0 = prof_event(e);
+            e1 = prof_event(e);
+            if (e0 < 0 || e1 < 0) { e1 = -1; return; }
+            (void)hipEventRecord(e->events[e0], e->stream);
+            e->ktimes.push_back({name, e0});
+        } else {
+            g_pp_prof.e = e;
+            g_pp_prof.tag = name;
+        }
     }
     ~ProfScope() {
         if (e1 >= 0) (void)hipEventRecord(e->events[e1], e->stream);
+        g_pp_prof.e = nullptr;
+        g_pp_prof.tag = nullptr;
     }
 };
 
@@ -207,8 +270,10 @@ bool bn_fold(pp_engine* e, const std::string& prefix, int c, std::vector<float>&
 }
 
 int upload(pp_engine* e, float** d, const std::vector<float>& h) {
-    int st = dalloc(e, d, h.size());
-    if (st) return st;
+    void* q = nullptr;
+    HIPCHK(e, hipMalloc(&q, (h.size() ? h.size() : 1) * sizeof(float)));
+    e->wallocs.push_back(q);   // released by the next pp_finalize_weights / pp_destroy
+    *d = (float*)q;
     HIPCHK(e, hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     return PP_OK;
 }
@@ -230,19 +295,28 @@ static inline float bf16_to_f32(uint16_t h) {
     return f;
 }
 std::vector<float> split_weights_bf16x3(const std::vector<float>& wt, int n_total, int cin) {
-    std::vector<uint16_t> out((size_t)n_total * cin * 3);
+    std::vector<uint16_t> out((size_t)n_total * cin * PP_NPIECE);
     const int nch = cin / 16;
     for (int n = 0; n < n_total; ++n)
         for (int c = 0; c < cin; ++c) {
             const float w = wt[(size_t)n * cin + c];
+#if PP_SPLIT_MODE == 0
             const uint16_t hi = bf16_rne(w);
             const float r1 = w - bf16_to_f32(hi);
             const uint16_t mid = bf16_rne(r1);
             const float r2 = r1 - bf16_to_f32(mid);
             const uint16_t lo = bf16_rne(r2);
+#else   // two float16 pieces (round-to-nearest-even conversions), the third slot of the layout stays zero
+            const _Float16 hf = (_Float16)w;
+            const _Float16 mf = (_Float16)(w - (float)hf);
+            uint16_t hi, mid;
+            memcpy(&hi, &hf, 2);
+            memcpy(&mid, &mf, 2);
+            const uint16_t lo = 0;
+#endif
             const int kc = c / 16, cc = c % 16;
             const uint16_t pcs[3] = {hi, mid, lo};
-            for (int p = 0; p < 3; ++p) out[(((size_t)kc * 3 + p) * n_total + n) * 16 + cc] = pcs[p];
+            for (int p = 0; p < PP_NPIECE; ++p) out[(((size_t)kc * PP_NPIECE + p) * n_total + n) * 16 + cc] = pcs[p];
         }
     (void)nch;
     std::vector<float> packed(out.size() / 2);
@@ -273,7 +347,7 @@ int run_voxelize(pp_engine* e, int batch, int max_n) {
     const bool lds_first = voxel_first_in_lds(max_n, e->ncell, e->cfg.max_voxels);
     int* d_first = lds_first ? nullptr : e->d_first;
     if (!lds_first) {
-        ProfScope ps(e, "memset_first");
+        ProfScope ps(e, "memset_first", true);
         HIPCHK(e, hipMemsetAsync(e->d_first, 0x7f, (size_t)batch * e->ncell * sizeof(int), e->stream));
     }
     {
@@ -284,8 +358,8 @@ int run_voxelize(pp_engine* e, int batch, int max_n) {
     {
         ProfScope ps(e, "k_voxel_frame");
         launch_voxel_frame(e->d_offsets, e->d_cell, d_first, e->d_cellmap, e->d_keyA, e->d_idxA, e->d_keyB,
-                           e->d_idxB, e->d_pstart, e->d_pcell, e->d_npillars, e->d_nvalid, batch, e->ncell,
-                           e->cfg.max_voxels, e->stream);
+                           e->d_idxB, e->d_pstart, e->d_pcell, e->d_npillars, e->d_nvalid, batch, max_n, e->ncell,
+                           e->cfg.max_voxels, e->d_points, e->d_points_sorted, e->F, e->stream);
     }
     HIPCHK(e, hipGetLastError());
     return PP_OK;
@@ -306,10 +380,11 @@ int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out) {
     p.x_off = (float)(e->cfg.voxel_size[0] / 2 + e->cfg.pc_range[0]);
     p.y_off = (float)(e->cfg.voxel_size[1] / 2 + e->cfg.pc_range[1]);
     p.w = e->d_pfn_w; p.bias = e->d_pfn_b; p.cellmap = e->d_cellmap;
-    p.pts = e->d_points; p.offsets = e->d_offsets; p.sorted_idx = sorted_idx(e); p.pillar_start = e->d_pstart;
+    p.pts_sorted = e->d_points_sorted; p.offsets = e->d_offsets; p.pillar_start = e->d_pstart;
     p.voxels = e->d_voxels; p.num_points = e->d_numpts;
     p.canvas = e->d_canvas; p.feat_out = feat_out;
     p.sparse = e->sparse_canvas ? 1 : 0;
+    p.with_distance = e->with_dist ? 1 : 0;
     ProfScope ps(e, "k_pfn_canvas:pfn+scatter");
     int st = launch_pfn(p, padded, e->stream);
     if (st) return fail(e, st, "PFN: unsupported C=%d / F=%d", e->C, e->F);
@@ -318,7 +393,7 @@ int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out) {
 }
 
 int run_anchor_mask(pp_engine* e, int batch) {
-    ProfScope ps(e, "anchor_mask:rowscan+colscan+lookup");
+    ProfScope ps(e, nullptr);   // three kernels, each under its own name
     launch_anchor_mask(e->d_cellmap, batch, e->nz, e->ny, e->nx, e->d_cells, e->A, e->cfg.anchor_area_threshold,
                        e->d_integ, e->d_mask, e->stream);
     HIPCHK(e, hipGetLastError());
@@ -334,6 +409,8 @@ void refresh_tags(pp_engine* e, int batch) {
 
 int run_backbone(pp_engine* e, int batch) {
     refresh_tags(e, batch);
+    e->cls_plane_live = false;
+    for (const LayerDesc& L : e->layers) if (layer_writes_cls_plane(L)) e->cls_plane_live = true;
     for (size_t i = 0; i < e->layers.size(); ++i) {
         const LayerDesc& L = e->layers[i];
         ProfScope ps(e, e->layer_tags[i].c_str());
@@ -348,7 +425,7 @@ int run_post(pp_engine* e, int batch) {
     PostParams p;
     p.batch = batch; p.A = e->A; p.pre_max = e->cfg.nms_pre_max_size; p.post_max = e->cfg.nms_post_max_size;
     p.score_thr = e->cfg.nms_score_threshold; p.iou_thr = e->cfg.nms_iou_threshold;
-    p.head = e->d_head; p.napl = e->napl; p.mask = e->d_mask; p.anchors = e->d_anchors;
+    p.head = e->d_head; p.cls = e->cls_plane_live ? e->d_cls : nullptr; p.napl = e->napl; p.ncls = e->ncls; p.use_dir = e->use_dir ? 1 : 0; p.mask = e->d_mask; p.anchors = e->d_anchors;
     p.calib = e->d_calib; p.dets = e->d_dets; p.n_dets = e->d_ndets;
     ProfScope ps(e, "k_postprocess");
     launch_postprocess(p, e->stream);
@@ -356,12 +433,24 @@ int run_post(pp_engine* e, int batch) {
     return PP_OK;
 }
 
+// The stage entry points (pp_points_to_voxel, pp_anchor_mask, pp_forward_voxels, pp_predict) reuse the fused
+// path's device buffers (points, cell map, canvas, head map, mask, detections): after one of them the resident
+// frames and the last results of the fused path are gone, and the calls that would read them say so.
+void stage_call_done(pp_engine* e) {
+    e->cur_batch = 0;
+    e->cur_max_n = 0;
+    e->results_batch = 0;
+}
+
 int check_batch(pp_engine* e, int batch) {
     if (batch < 1 || batch > e->B) return fail(e, PP_ERR_ARG, "batch %d outside [1, max_batch=%d]", batch, e->B);
     return PP_OK;
 }
 
-int set_offsets(pp_engine* e, const int32_t* off, int batch) {
+// Validates the frame offsets, flips to the other input buffer and queues the offsets' copy on `stream`
+// (the main stream, or the copy stream for the asynchronous upload -- which first waits until the pass that
+// last read that buffer has finished).
+int set_offsets(pp_engine* e, const int32_t* off, int batch, hipStream_t stream) {
     if (!off) return fail(e, PP_ERR_ARG, "frame_offsets is NULL");
     if (off[0] != 0) return fail(e, PP_ERR_ARG, "frame_offsets[0] must be 0");
     int max_n = 0;
@@ -371,17 +460,27 @@ int set_offsets(pp_engine* e, const int32_t* off, int batch) {
         if (n > e->NMAX) return fail(e, PP_ERR_ARG, "frame %d has %d points > max_points_per_frame=%d", b, n, e->NMAX);
         if (n > max_n) max_n = n;
     }
-    e->h_offsets.assign(off, off + batch + 1);
+    const int slot = e->off_slot;
+    e->off_slot = (slot + 1) % pp_engine::OFF_RING;
+    HIPCHK(e, hipEventSynchronize(e->off_ev[slot]));   // the copy that last used this slot has been consumed
+    int* ring = e->h_off_ring + (size_t)slot * (e->B + 1);
+    memcpy(ring, off, (size_t)(batch + 1) * sizeof(int));
     e->cur_batch = batch;
     e->cur_max_n = max_n;
-    HIPCHK(e, hipMemcpyAsync(e->d_offsets, e->h_offsets.data(), (batch + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    const int nb = e->in_buf ^ 1;
+    e->in_buf = nb;
+    e->d_points = e->d_points_buf[nb];
+    e->d_offsets = e->d_offsets_buf[nb];
+    HIPCHK(e, hipStreamWaitEvent(stream, e->ev_read[nb], 0));   // (a no-op on the main stream, which is ordered anyway)
+    HIPCHK(e, hipMemcpyAsync(e->d_offsets, ring, (batch + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(e, hipEventRecord(e->off_ev[slot], stream));
     return PP_OK;
 }
 
 // fused head map [pixels][PP_HEAD_COLS] <-> the reference's three NHWC head tensors
 int fetch_heads(pp_engine* e, int batch, float* box, float* cls, float* dir) {
     const size_t px = (size_t)batch * e->head_h * e->head_w;
-    const int nb = e->napl * 7, nc = e->napl, nd = e->napl * 2;
+    const int nb = e->napl * 7, nc = e->napl * e->ncls, nd = e->use_dir ? e->napl * 2 : 0;
     std::vector<float> h(px * PP_HEAD_COLS);
     HIPCHK(e, hipMemcpyAsync(h.data(), e->d_head, h.size() * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -389,23 +488,24 @@ int fetch_heads(pp_engine* e, int batch, float* box, float* cls, float* dir) {
         const float* r = h.data() + p * PP_HEAD_COLS;
         if (box) memcpy(box + p * nb, r, nb * sizeof(float));
         if (cls) memcpy(cls + p * nc, r + nb, nc * sizeof(float));
-        if (dir) memcpy(dir + p * nd, r + nb + nc, nd * sizeof(float));
+        if (dir && nd) memcpy(dir + p * nd, r + nb + nc, nd * sizeof(float));
     }
     return PP_OK;
 }
 
 int upload_heads(pp_engine* e, int batch, const float* box, const float* cls, const float* dir) {
     const size_t px = (size_t)batch * e->head_h * e->head_w;
-    const int nb = e->napl * 7, nc = e->napl, nd = e->napl * 2;
+    const int nb = e->napl * 7, nc = e->napl * e->ncls, nd = e->use_dir ? e->napl * 2 : 0;
     std::vector<float> h(px * PP_HEAD_COLS, 0.f);
     for (size_t p = 0; p < px; ++p) {
         float* r = h.data() + p * PP_HEAD_COLS;
         memcpy(r, box + p * nb, nb * sizeof(float));
         memcpy(r + nb, cls + p * nc, nc * sizeof(float));
-        memcpy(r + nb + nc, dir + p * nd, nd * sizeof(float));
+        if (nd) memcpy(r + nb + nc, dir + p * nd, nd * sizeof(float));
     }
     HIPCHK(e, hipMemcpyAsync(e->d_head, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));   // h is a local
+    e->cls_plane_live = false;                    // the compact plane no longer mirrors the head map
     return PP_OK;
 }
 
@@ -435,9 +535,10 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
         return fail(nullptr, PP_ERR_ARG, "pp_create: max_points / max_voxels / max_batch / max_points_per_frame must be >= 1");
     if (cfg->num_point_features != 3 && cfg->num_point_features != 4)
         return fail(nullptr, PP_ERR_UNSUPPORTED, "pp_create: num_point_features must be 3 or 4");
-    if (cfg->num_class != 1) return fail(nullptr, PP_ERR_UNSUPPORTED, "pp_create: only num_class == 1 is implemented (as in the reference's predict())");
-    if (cfg->num_anchor_per_loc < 1 || cfg->num_anchor_per_loc * 10 > 32)
-        return fail(nullptr, PP_ERR_UNSUPPORTED, "pp_create: num_anchor_per_loc must be 1..3");
+    if (cfg->num_class < 1) return fail(nullptr, PP_ERR_ARG, "pp_create: num_class must be >= 1");
+    if (cfg->num_anchor_per_loc < 1 ||
+        cfg->num_anchor_per_loc * (7 + cfg->num_class + (cfg->use_direction_classifier ? 2 : 0)) > PP_HEAD_COLS)
+        return fail(nullptr, PP_ERR_UNSUPPORTED, "pp_create: num_anchor_per_loc * (7 + num_class + 2) must fit the %d-column head row", PP_HEAD_COLS);
     if (cfg->nms_post_max_size < 1 || cfg->nms_pre_max_size < 1)
         return fail(nullptr, PP_ERR_ARG, "pp_create: nms sizes must be >= 1");
     int ndev = 0;
@@ -467,7 +568,9 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
     e->nx = e->geom.grid[0]; e->ny = e->geom.grid[1]; e->nz = e->geom.grid[2];
     e->ncell = e->nx * e->ny * e->nz;
     e->geom.ncell = e->ncell;
-    e->C = cfg->pfn_filters; e->F = cfg->num_point_features; e->T = cfg->max_points; e->FA = e->F + 5;
+    e->C = cfg->pfn_filters; e->F = cfg->num_point_features; e->T = cfg->max_points;
+    e->ncls = cfg->num_class; e->use_dir = cfg->use_direction_classifier != 0; e->with_dist = cfg->with_distance != 0;
+    e->FA = e->F + 5 + (e->with_dist ? 1 : 0);
     e->B = cfg->max_batch; e->NMAX = cfg->max_points_per_frame;
     e->napl = cfg->num_anchor_per_loc;
     const int osf = cfg->layer_strides[0] / cfg->upsample_strides[0];
@@ -539,8 +642,13 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             const size_t BMV = (size_t)e->B * cfg->max_voxels;
             const size_t HW = (size_t)e->head_h * e->head_w;
             auto A1 = [&](int s) { if (st2 == PP_OK) st2 = s; };
-            A1(dalloc(q, &e->d_points, BN * e->F));
-            A1(dalloc(q, &e->d_offsets, (size_t)e->B + 1));
+            A1(dalloc(q, &e->d_points_buf[0], BN * e->F));
+            A1(dalloc(q, &e->d_points_buf[1], BN * e->F));
+            A1(dalloc(q, &e->d_offsets_buf[0], (size_t)e->B + 1));
+            A1(dalloc(q, &e->d_offsets_buf[1], (size_t)e->B + 1));
+            e->d_points = e->d_points_buf[0];
+            e->d_offsets = e->d_offsets_buf[0];
+            A1(dalloc(q, &e->d_points_sorted, BN * e->F));
             A1(dalloc(q, &e->d_cell, BN));
             A1(dalloc(q, &e->d_first, (size_t)e->B * e->ncell));
             A1(dalloc(q, &e->d_cellmap, (size_t)e->B * e->ncell));
@@ -562,6 +670,7 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             APAD(&e->d_act[1], act_max);
             if (!e->fuse_heads) APAD(&e->d_concat, (size_t)e->B * HW * e->CC);
             A1(dalloc(q, &e->d_head, (size_t)e->B * HW * PP_HEAD_COLS));
+            A1(dalloc(q, &e->d_cls, (size_t)e->B * HW * e->napl * e->ncls));
             A1(dalloc(q, &e->d_integ, (size_t)e->B * e->ny * e->nx));
             A1(dalloc(q, &e->d_mask, (size_t)e->B * e->A));
             A1(dalloc(q, &e->d_anchors, (size_t)e->A * 7));
@@ -572,6 +681,20 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             if (st2 == PP_OK && hipHostMalloc((void**)&e->h_dets, (size_t)e->B * cfg->nms_post_max_size * sizeof(pp_detection)) != hipSuccess) st2 = PP_ERR_HIP;
             if (st2 == PP_OK && hipHostMalloc((void**)&e->h_ndets, (size_t)e->B * sizeof(int)) != hipSuccess) st2 = PP_ERR_HIP;
             if (st2 == PP_OK && (hipEventCreate(&e->t0) != hipSuccess || hipEventCreate(&e->t1) != hipSuccess)) st2 = PP_ERR_HIP;
+            if (st2 == PP_OK && hipHostMalloc((void**)&e->h_off_ring, (size_t)pp_engine::OFF_RING * (e->B + 1) * sizeof(int)) != hipSuccess) st2 = PP_ERR_HIP;
+            for (int i = 0; i < pp_engine::OFF_RING && st2 == PP_OK; ++i)
+                if (hipEventCreateWithFlags(&e->off_ev[i], hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
+            if (st2 == PP_OK && hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
+            if (st2 == PP_OK && hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
+            for (int i = 0; i < 2 && st2 == PP_OK; ++i)
+                if (hipEventCreateWithFlags(&e->ev_read[i], hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
+            if (st2 == PP_OK) {
+                // one upload stream per device, shared by every handle: the host link is one resource, and the
+                // runtime multiplexes streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, default 4) --
+                // a private copy stream per handle made the handles' compute streams share queues and serialise
+                e->copy_stream = device_copy_stream(device);
+                if (e->copy_stream == nullptr) st2 = PP_ERR_HIP;
+            }
             if (st2 == PP_OK) {
                 // identity calibration until pp_set_calib
                 std::vector<float> I((size_t)e->B * 16, 0.f);
@@ -586,6 +709,15 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             e->layer_tags.assign(e->layers.size(), std::string());
             const float* cur = e->d_canvas;
             int pp = 0;
+            if (e->fuse_heads && !getenv("PP_NO_CLS_PLANE")) {   // the last branch finishes the head sums
+                LayerDesc* last = nullptr;
+                for (LayerDesc& L : e->layers) if (L.kind == LAYER_DECONV) last = &L;
+                if (last && last->head_mode == 2) {
+                    last->d_cls_plane = e->d_cls;
+                    last->cls_col0 = e->napl * 7;
+                    last->cls_ncol = e->napl * e->ncls;
+                }
+            }
             for (LayerDesc& L : e->layers) {
                 if (L.kind == LAYER_SEP) { L.in = cur; L.out = e->d_act[pp]; cur = L.out; pp ^= 1; }
                 else if (L.kind == LAYER_DECONV) { L.in = cur; L.out = e->fuse_heads ? nullptr : e->d_concat; }
@@ -603,9 +735,16 @@ static void graph_invalidate(pp_engine* e);
 int pp_destroy(pp_handle e) {
     if (!e) return PP_OK;
     (void)hipSetDevice(e->device);
+    if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     graph_invalidate(e);
     for (void* p : e->allocs) (void)hipFree(p);
+    for (void* p : e->wallocs) (void)hipFree(p);
+    if (e->h_off_ring) (void)hipHostFree(e->h_off_ring);
+    for (hipEvent_t ev : e->off_ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_up) (void)hipEventDestroy(e->ev_up);
+    for (hipEvent_t ev : e->ev_read) if (ev) (void)hipEventDestroy(ev);
     if (e->d_voxels) (void)hipFree(e->d_voxels);
     if (e->d_numpts) (void)hipFree(e->d_numpts);
     if (e->d_coors) (void)hipFree(e->d_coors);
@@ -633,9 +772,12 @@ int pp_set_weight(pp_handle e, const char* name, const float* data, const int64_
 }
 
 int pp_finalize_weights(pp_handle e) {
-    if (e) graph_invalidate(e);   // weight buffers are re-allocated below
     if (!e) return PP_ERR_ARG;
     (void)hipSetDevice(e->device);
+    graph_invalidate(e);          // waits for the stream; the captured graphs hold the old weight pointers
+    e->weights_ready = false;
+    for (void* p : e->wallocs) (void)hipFree(p);   // the previous weight set (the stream is idle)
+    e->wallocs.clear();
     std::vector<float> sc, sh;
     // PFN: dense [Fa,C] * scale, bias = shift
     {
@@ -650,22 +792,26 @@ int pp_finalize_weights(pp_handle e) {
     // the three head kernels as one [PP_HEAD_COLS][CC] matrix (rows: box | cls | dir | zero pad) + bias
     std::vector<float> headw((size_t)PP_HEAD_COLS * e->CC, 0.f), headb(PP_HEAD_COLS, 0.f);
     {
-        const int nb = e->napl * 7, nc = e->napl, nd = e->napl * 2, CC = e->CC;
+        const int nb = e->napl * 7, nc = e->napl * e->ncls, nd = e->use_dir ? e->napl * 2 : 0, CC = e->CC;
         const auto* kb = getw(e, "rpn/conv_box/kernel", {1, 1, CC, nb});
         const auto* bb = getw(e, "rpn/conv_box/bias", {nb});
         const auto* kc = getw(e, "rpn/conv_cls/kernel", {1, 1, CC, nc});
         const auto* bc = getw(e, "rpn/conv_cls/bias", {nc});
-        const auto* kd = getw(e, "rpn/conv_dir_cls/kernel", {1, 1, CC, nd});
-        const auto* bd = getw(e, "rpn/conv_dir_cls/bias", {nd});
-        if (!kb || !bb || !kc || !bc || !kd || !bd) return PP_ERR_SHAPE;
+        if (!kb || !bb || !kc || !bc) return PP_ERR_SHAPE;
         for (int ci = 0; ci < CC; ++ci) {
             for (int o = 0; o < nb; ++o) headw[(size_t)o * CC + ci] = (*kb)[(size_t)ci * nb + o];
             for (int o = 0; o < nc; ++o) headw[(size_t)(nb + o) * CC + ci] = (*kc)[(size_t)ci * nc + o];
-            for (int o = 0; o < nd; ++o) headw[(size_t)(nb + nc + o) * CC + ci] = (*kd)[(size_t)ci * nd + o];
         }
         for (int o = 0; o < nb; ++o) headb[o] = (*bb)[o];
         for (int o = 0; o < nc; ++o) headb[nb + o] = (*bc)[o];
-        for (int o = 0; o < nd; ++o) headb[nb + nc + o] = (*bd)[o];
+        if (e->use_dir) {   // model/voxelnet.py:690: the direction head exists only with use_direction_classifier
+            const auto* kd = getw(e, "rpn/conv_dir_cls/kernel", {1, 1, CC, nd});
+            const auto* bd = getw(e, "rpn/conv_dir_cls/bias", {nd});
+            if (!kd || !bd) return PP_ERR_SHAPE;
+            for (int ci = 0; ci < CC; ++ci)
+                for (int o = 0; o < nd; ++o) headw[(size_t)(nb + nc + o) * CC + ci] = (*kd)[(size_t)ci * nd + o];
+            for (int o = 0; o < nd; ++o) headb[nb + nc + o] = (*bd)[o];
+        }
     }
     int bi = 0, li = 0;
     for (LayerDesc& L : e->layers) {
@@ -758,7 +904,8 @@ int pp_upload_points(pp_handle e, const float* points, const int32_t* frame_offs
     if (!e) return PP_ERR_ARG;
     (void)hipSetDevice(e->device);
     int st = check_batch(e, batch); if (st) return st;
-    st = set_offsets(e, frame_offsets, batch); if (st) return st;
+    st = set_offsets(e, frame_offsets, batch, e->stream); if (st) return st;
+    e->up_pending = false;
     const size_t n = (size_t)frame_offsets[batch];
     if (n && !points) return fail(e, PP_ERR_ARG, "pp_upload_points: points is NULL");
     if (n) HIPCHK(e, hipMemcpyAsync(e->d_points, points, n * e->F * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -766,14 +913,59 @@ int pp_upload_points(pp_handle e, const float* points, const int32_t* frame_offs
     return PP_OK;
 }
 
-int pp_upload_points_device(pp_handle e, const void* points_dev, const int32_t* frame_offsets, int32_t batch) {
+int pp_upload_points_async(pp_handle e, const float* points_pinned, const int32_t* frame_offsets, int32_t batch) {
     if (!e) return PP_ERR_ARG;
     (void)hipSetDevice(e->device);
     int st = check_batch(e, batch); if (st) return st;
-    st = set_offsets(e, frame_offsets, batch); if (st) return st;
+    if (frame_offsets && batch >= 1 && frame_offsets[batch] > 0 && !points_pinned)
+        return fail(e, PP_ERR_ARG, "pp_upload_points_async: points is NULL");
+    // on the copy stream, into the input buffer the running pass is not reading: no wait here, and the DMA runs
+    // beside this handle's own kernels; pp_detect_async orders itself behind ev_up
+    st = set_offsets(e, frame_offsets, batch, e->copy_stream); if (st) return st;
+    const size_t n = (size_t)frame_offsets[batch];
+    if (n) HIPCHK(e, hipMemcpyAsync(e->d_points, points_pinned, n * e->F * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
+    HIPCHK(e, hipEventRecord(e->ev_up, e->copy_stream));
+    e->up_pending = true;
+    return PP_OK;
+}
+
+int pp_host_alloc(int64_t bytes, void** out) {
+    if (!out || bytes < 0) return fail(nullptr, PP_ERR_ARG, "pp_host_alloc: bad argument");
+    *out = nullptr;
+    if (hipHostMalloc(out, (size_t)(bytes ? bytes : 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, PP_ERR_HIP, "pp_host_alloc: hipHostMalloc(%lld) failed", (long long)bytes);
+    }
+    return PP_OK;
+}
+
+int pp_host_free(void* p) {
+    if (p && hipHostFree(p) != hipSuccess) return fail(nullptr, PP_ERR_HIP, "pp_host_free: hipHostFree failed");
+    return PP_OK;
+}
+
+int pp_upload_points_device(pp_handle e, const void* points_dev, const int32_t* frame_offsets, int32_t batch,
+                            void* producer_stream) {
+    if (!e) return PP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    int st = check_batch(e, batch); if (st) return st;
+    st = set_offsets(e, frame_offsets, batch, e->stream); if (st) return st;
+    e->up_pending = false;
     const size_t n = (size_t)frame_offsets[batch];
     if (n && !points_dev) return fail(e, PP_ERR_ARG, "pp_upload_points_device: points is NULL");
+    if (producer_stream != nullptr) {
+        // the copy must not start before the work queued on the producer's stream has written the points
+        HIPCHK(e, hipEventRecord(e->ev_in, (hipStream_t)producer_stream));
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_in, 0));
+    }
     if (n) HIPCHK(e, hipMemcpyAsync(e->d_points, points_dev, n * e->F * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    return PP_OK;
+}
+
+int pp_current_batch(pp_handle e, int32_t* uploaded, int32_t* results) {
+    if (!e) return PP_ERR_ARG;
+    if (uploaded) *uploaded = e->cur_batch;
+    if (results) *results = e->results_batch;
     return PP_OK;
 }
 
@@ -789,6 +981,9 @@ int pp_set_calib(pp_handle e, const float* rect, const float* trv2c, int32_t bat
 }
 
 static void graph_invalidate(pp_engine* e) {
+    // a replay of one of these graphs may still be running on the stream: its kernarg / node storage must
+    // outlive it
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& g : e->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         g = pp_engine::GraphSlot();
@@ -835,6 +1030,10 @@ int pp_detect_async(pp_handle e) {
     (void)hipSetDevice(e->device);
     const int B = e->cur_batch;
     prof_reset(e);
+    if (e->up_pending) {   // the frames were uploaded on the copy stream
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_up, 0));
+        e->up_pending = false;
+    }
     // ~35 launches per batch replay as ONE graph launch: every kernel argument is a device pointer or a
     // per-(batch, max points) constant, so the captured graph is reusable until either changes (profiling
     // needs the per-launch events and uses plain launches)
@@ -843,12 +1042,16 @@ int pp_detect_async(pp_handle e) {
         pp_engine::GraphSlot* slot = nullptr;
         pp_engine::GraphSlot* lru = &e->graphs[0];
         for (auto& g : e->graphs) {
-            if (g.exec && g.batch == B && g.bucket == bucket) slot = &g;
+            if (g.exec && g.batch == B && g.bucket == bucket && g.buf == e->in_buf) slot = &g;
             if (g.used < lru->used) lru = &g;
         }
         if (slot == nullptr) {
             slot = lru;
-            if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
+            if (slot->exec) {
+                // LRU eviction: the evicted graph may still be replaying (pp_detect_async does not wait)
+                HIPCHK(e, hipStreamSynchronize(e->stream));
+                (void)hipGraphExecDestroy(slot->exec);
+            }
             *slot = pp_engine::GraphSlot();
             hipGraph_t g = nullptr;
             bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -857,6 +1060,7 @@ int pp_detect_async(pp_handle e) {
             if (ok && st == PP_OK && g != nullptr && hipGraphInstantiate(&slot->exec, g, nullptr, nullptr, 0) == hipSuccess) {
                 slot->batch = B;
                 slot->bucket = bucket;
+                slot->buf = e->in_buf;
             } else {
                 slot->exec = nullptr;
                 e->graph_state = -1;           // fall back to plain launches for the life of the handle
@@ -867,10 +1071,17 @@ int pp_detect_async(pp_handle e) {
         if (slot->exec != nullptr) {
             slot->used = ++e->graph_tick;
             HIPCHK(e, hipGraphLaunch(slot->exec, e->stream));
+            HIPCHK(e, hipEventRecord(e->ev_read[e->in_buf], e->stream));
+            e->results_batch = B;
             return PP_OK;
         }
     }
-    return enqueue_detect(e, B, e->cur_max_n);
+    int st = enqueue_detect(e, B, e->cur_max_n);
+    if (st == PP_OK) {
+        HIPCHK(e, hipEventRecord(e->ev_read[e->in_buf], e->stream));
+        e->results_batch = B;
+    }
+    return st;
 }
 
 int pp_sync(pp_handle e) {
@@ -883,7 +1094,10 @@ int pp_sync(pp_handle e) {
 int pp_get_detections(pp_handle e, pp_detection* dets, int32_t* n_dets) {
     if (!e) return PP_ERR_ARG;
     if (!dets || !n_dets) return fail(e, PP_ERR_ARG, "pp_get_detections: NULL argument");
-    const int B = e->cur_batch;
+    const int B = e->results_batch;
+    if (B < 1) return fail(e, PP_ERR_STATE, "pp_get_detections: no pp_detect_async results on this handle (or a stage call has reused the buffers)");
+    (void)hipSetDevice(e->device);
+    HIPCHK(e, hipStreamSynchronize(e->stream));   // immediate after pp_sync; never hands out a half-written buffer
     memcpy(dets, e->h_dets, (size_t)B * e->cfg.nms_post_max_size * sizeof(pp_detection));
     memcpy(n_dets, e->h_ndets, (size_t)B * sizeof(int));
     return PP_OK;
@@ -913,7 +1127,7 @@ int pp_points_to_voxel(pp_handle e, const float* points, int64_t n, float* voxel
     if ((st = dgrow(e, &e->d_voxels, &e->cap_voxels, MV * e->T * e->F))) return st;
     if ((st = dgrow(e, &e->d_numpts, &e->cap_numpts, MV))) return st;
     if ((st = dgrow(e, &e->d_coors, &e->cap_coors, MV * 4))) return st;
-    launch_voxel_expand(e->d_points, e->d_offsets, sorted_idx(e), e->d_pstart, e->d_pcell, e->d_npillars, 0, e->F,
+    launch_voxel_expand(e->d_points_sorted, e->d_offsets, sorted_idx(e), e->d_pstart, e->d_pcell, e->d_npillars, 0, e->F,
                         e->T, e->cfg.max_voxels, e->ny, e->nx, e->d_voxels, e->d_coors, e->d_numpts, e->stream);
     HIPCHK(e, hipGetLastError());
     int P = 0;
@@ -926,6 +1140,7 @@ int pp_points_to_voxel(pp_handle e, const float* points, int64_t n, float* voxel
         HIPCHK(e, hipMemcpy(coors, e->d_coors, (size_t)P * 3 * sizeof(int), hipMemcpyDeviceToHost));
         HIPCHK(e, hipMemcpy(num_points, e->d_numpts, (size_t)P * sizeof(int), hipMemcpyDeviceToHost));
     }
+    stage_call_done(e);
     return PP_OK;
 }
 
@@ -955,6 +1170,7 @@ int pp_anchor_mask(pp_handle e, const int32_t* coors, int64_t num_pillars, int32
     if ((st = run_anchor_mask(e, batch))) return st;
     HIPCHK(e, hipMemcpyAsync(mask, e->d_mask, (size_t)batch * e->A, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    stage_call_done(e);
     return PP_OK;
 }
 
@@ -963,7 +1179,7 @@ int pp_forward_voxels(pp_handle e, const float* voxels, const int32_t* num_point
                       float* pillar_features, float* canvas) {
     if (!e) return PP_ERR_ARG;
     if (!e->weights_ready) return fail(e, PP_ERR_STATE, "pp_forward_voxels: weights not finalised");
-    if (P < 0 || (P && (!voxels || !num_points || !coors)) || !box_preds || !cls_preds || !dir_cls_preds)
+    if (P < 0 || (P && (!voxels || !num_points || !coors)) || !box_preds || !cls_preds || (e->use_dir && !dir_cls_preds))
         return fail(e, PP_ERR_ARG, "pp_forward_voxels: NULL argument");
     (void)hipSetDevice(e->device);
     int st = check_batch(e, batch); if (st) return st;
@@ -986,6 +1202,7 @@ int pp_forward_voxels(pp_handle e, const float* voxels, const int32_t* num_point
         HIPCHK(e, hipMemcpyAsync(pillar_features, e->d_feat, (size_t)P * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (canvas && (st = fetch_canvas(e, canvas, batch))) return st;
+    stage_call_done(e);
     return PP_OK;
 }
 
@@ -994,7 +1211,7 @@ int pp_predict(pp_handle e, const float* box_preds, const float* cls_preds, cons
                pp_detection* dets, int32_t* n_dets) {
     if (!e) return PP_ERR_ARG;
     if (!e->anchors_ready) return fail(e, PP_ERR_STATE, "pp_predict: anchors not set");
-    if (!box_preds || !cls_preds || !dir_cls_preds || !anchors_mask || !rect || !trv2c || !dets || !n_dets)
+    if (!box_preds || !cls_preds || (e->use_dir && !dir_cls_preds) || !anchors_mask || !rect || !trv2c || !dets || !n_dets)
         return fail(e, PP_ERR_ARG, "pp_predict: NULL argument");
     (void)hipSetDevice(e->device);
     int st = check_batch(e, batch); if (st) return st;
@@ -1006,6 +1223,7 @@ int pp_predict(pp_handle e, const float* box_preds, const float* cls_preds, cons
     HIPCHK(e, hipMemcpyAsync(dets, e->d_dets, (size_t)batch * e->cfg.nms_post_max_size * sizeof(pp_detection), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipMemcpyAsync(n_dets, e->d_ndets, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    stage_call_done(e);
     return PP_OK;
 }
 
@@ -1014,8 +1232,8 @@ int pp_fetch_intermediates(pp_handle e, int32_t* n_pillars, int32_t* coors, int3
                            float* canvas) {
     if (!e) return PP_ERR_ARG;
     (void)hipSetDevice(e->device);
-    const int B = e->cur_batch;
-    if (B < 1) return fail(e, PP_ERR_STATE, "pp_fetch_intermediates: nothing has run");
+    const int B = e->results_batch;
+    if (B < 1) return fail(e, PP_ERR_STATE, "pp_fetch_intermediates: no fused-path pass to tap (run pp_detect / pp_detect_async first)");
     HIPCHK(e, hipStreamSynchronize(e->stream));
     const int MV = e->cfg.max_voxels;
     std::vector<int> np(B);
@@ -1225,7 +1443,7 @@ int pp_head_loss(pp_handle e, const int32_t* labels, const float* reg_targets, i
     int st = check_batch(e, batch);
     if (st) return st;
     if (!(lc->sigma > 0.f)) return fail(e, PP_ERR_ARG, "pp_head_loss: sigma must be positive");
-    if (e->cfg.num_class != 1) return fail(e, PP_ERR_UNSUPPORTED, "pp_head_loss: one class only (like the reference's predict)");
+    if (e->cfg.num_class != 1 || !e->use_dir) return fail(e, PP_ERR_UNSUPPORTED, "pp_head_loss: one class with the direction head only (the shipped training config)");
     (void)hipSetDevice(e->device);
     const size_t npx = (size_t)e->head_h * e->head_w;
     if (!e->d_head_grad) {   // training-side buffers: allocated on first use
@@ -1251,7 +1469,7 @@ int pp_head_loss(pp_handle e, const int32_t* labels, const float* reg_targets, i
     p.norm_by_num_positives = lc->norm_by_num_positives; p.encode_rad_error_by_sin = lc->encode_rad_error_by_sin;
     p.use_direction = lc->use_direction_classifier;
     {
-        ProfScope ps(e, "k_loss_pixels:loss+grad");
+        ProfScope ps(e, "k_loss_pixels:loss+grad", true);
         if ((st = launch_head_loss(p, e->stream))) return fail(e, st, "pp_head_loss: %d anchors per pixel not supported", e->napl);
     }
     HIPCHK(e, hipGetLastError());

@@ -9,14 +9,43 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "../../include/pp_hip.h"
 
 #define PP_WAVE 64
+// split-precision operand pieces of the GEMM kernels (backbone.hip explains the modes); pp_api.hip splits the
+// weights accordingly.  A build-time choice: -DPP_SPLIT_MODE=n
+#ifndef PP_SPLIT_MODE
+#define PP_SPLIT_MODE 1
+#endif
+// pieces per value in the pre-split weight layouts ([cin/16][PP_NPIECE][n][16] 16-bit words)
+#define PP_NPIECE ((PP_SPLIT_MODE == 0) ? 3 : 2)
 // zeroed floats in front of every activation buffer (>= the widest layer input, 384 channels):
 // the GEMM producers read convolution zero-padding from there instead of masking loaded values
 #define PP_ZPAD_FLOATS 512
-// fused head map: one 128-byte row per head-map pixel: [box napl*7 | cls napl | dir napl*2 | 0 pad]
+// fused head map: one 128-byte row per head-map pixel: [box napl*7 | cls napl*ncls | dir napl*2 | 0 pad]
 #define PP_HEAD_COLS 32
+
+// ----- kernel launches ----------------------------------------------------
+// Every hot-path kernel is launched through PP_LAUNCH.  Normally that is a plain hipLaunchKernelGGL.  While a
+// handle collects per-kernel times (pp_set_profiling; plain launches, never inside a graph capture) the launch
+// carries a start / stop event pair of its own (hipExtLaunchKernelGGL): the pair brackets the kernel's execution
+// on the device -- the same interval rocprofv3's kernel trace reports -- not the gaps between launches.
+struct PpProf {
+    pp_engine* e;       // handle collecting times on this thread (NULL: none)
+    const char* tag;    // name to record ("<kernel symbol>:<layer>"), or NULL: the launch site's own name
+};
+extern thread_local PpProf g_pp_prof;
+bool pp_prof_events(const char* name, hipEvent_t* start, hipEvent_t* stop);   // pp_api.hip
+#define PP_LAUNCH(NAME, KERNEL, GRID, BLOCK, SHMEM, STREAM, ...)                                            \
+    do {                                                                                                    \
+        hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                                          \
+        if (g_pp_prof.e != nullptr && pp_prof_events(NAME, &pe0_, &pe1_))                                   \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, pe0_, pe1_, 0, __VA_ARGS__);          \
+        else                                                                                                \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, __VA_ARGS__);                            \
+    } while (0)
 
 // ----- voxel grid geometry (float64, as the reference's index math) -----
 struct VoxGeom {
@@ -54,6 +83,9 @@ struct LayerDesc {
     // cell holds no pillar is read from the zero header instead of the (unwritten) canvas.  NULL: dense input
     const int* d_occ;
     int occ_nz;
+    // compact class-logit plane [B * H' * W'][cls_ncol], written by the LAST fused-head deconv (NULL elsewhere)
+    float* d_cls_plane;
+    int cls_col0, cls_ncol;
     const char* name;
 };
 
@@ -65,8 +97,10 @@ int voxel_sort_passes(int max_voxels);
 bool voxel_first_in_lds(int max_n, int ncell, int max_voxels);   // pass first = NULL to both launchers below
 void launch_voxel_frame(const int* offsets, const int* cell, const int* first, int* cellmap, unsigned* keyA,
                         unsigned* idxA, unsigned* keyB, unsigned* idxB, int* pillar_start, int* pillar_cell,
-                        int* npillars, int* nvalid, int batch, int ncell, int max_voxels, hipStream_t s);
-void launch_voxel_expand(const float* pts, const int* offsets, const unsigned* sorted_idx, const int* pillar_start,
+                        int* npillars, int* nvalid, int batch, int max_n, int ncell, int max_voxels, const float* pts,
+                        float* pts_sorted, int F, hipStream_t s);
+// pts_sorted: the pillar-sorted copy k_voxel_frame leaves ([sum N][F], frame b's valid points at offsets[b]..)
+void launch_voxel_expand(const float* pts_sorted, const int* offsets, const unsigned* sorted_idx, const int* pillar_start,
                          const int* pillar_cell, const int* npillars, int frame, int F, int T, int max_voxels,
                          int ny, int nx, float* voxels, int* coors, int* num_points, hipStream_t s);
 void launch_build_cellmap(const int* coors4, int64_t P, int ncell, int ny, int nx, int* cellmap, hipStream_t s);
@@ -80,10 +114,9 @@ struct PfnParams {
     const float* bias;
     // cell -> pillar map [batch][nz][ny][nx]
     const int* cellmap;
-    // CSR source (raw points)
-    const float* pts;
+    // CSR source: pillar-sorted points (frame b: rows offsets[b] + pillar_start[b][p] .. of pts_sorted)
+    const float* pts_sorted;
     const int* offsets;
-    const unsigned* sorted_idx;
     const int* pillar_start;
     // padded source (compat)
     const float* voxels;
@@ -91,6 +124,7 @@ struct PfnParams {
     // outputs
     float* canvas;    // [batch][ny][nx][C]
     int sparse;       // 1: only cells that hold a pillar are written (the first layer consults the cell map)
+    int with_distance;  // 1: one more input feature, the point's Euclidean norm (w has F + 6 rows)
     float* feat_out;  // optional [P][C]
 };
 int launch_pfn(const PfnParams& p, bool padded_source, hipStream_t s);  // returns 0 or PP_ERR_UNSUPPORTED
@@ -99,6 +133,7 @@ void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, c
                         float threshold, int* integ, uint8_t* mask, hipStream_t s);
 
 bool deconv_can_fuse_heads(const LayerDesc& L);
+bool layer_writes_cls_plane(const LayerDesc& L);   // does this layer's kernel leave the compact class-logit plane?
 bool sparse_input_supported(const LayerDesc& L, int batch);   // may L's input be a canvas with unwritten empty cells?
 std::string layer_kernel_name(const LayerDesc& L, int batch);  // template instantiation that runs L at this batch
 int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s,
@@ -110,7 +145,11 @@ struct PostParams {
     int pre_max, post_max;
     float score_thr, iou_thr;
     const float* head;     // [batch][H'*W'][PP_HEAD_COLS] fused head map
+    const float* cls;      // compact class logits [batch][H'*W'][napl*ncls] (same values as the head map's cls
+                           // columns), or NULL: the candidate scan reads the head rows
     int napl;              // anchors per location
+    int ncls;              // class logits per anchor (score = max, label = argmax)
+    int use_dir;           // 0: no direction head, no flip
     const uint8_t* mask;   // [batch][A]
     const float* anchors;  // [A][7]
     const float* calib;    // [batch][16]  rect @ Trv2c (float32)

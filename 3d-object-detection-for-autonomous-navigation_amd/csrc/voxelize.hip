@@ -101,20 +101,26 @@ int voxel_sort_passes(int max_voxels) {
     return (bits + 7) / 8;
 }
 
-// BITS: digit width of the radix passes as a compile-time constant (the ballot loops unroll), 0 = run time
-template <int BITS>
+// BITS: digit width of the radix passes as a compile-time constant (the ballot loops unroll), 0 = run time.
+// PPT: points per thread of the register / LDS path -- 16 (frames up to 16 384 points; the upper half of the
+// 128 KB sort buffer then carries the first-point / pillar-id tables of grids up to 16 384 cells) or 32 (frames up
+// to 32 768 points, KITTI-sized clouds: the whole buffer is sort space, the cell tables stay in global memory).
+template <int BITS, int PPT>
 __global__ __launch_bounds__(VT) void k_voxel_frame(
     const int* __restrict__ offsets, const int* __restrict__ cell, const int* __restrict__ first,
     int* __restrict__ cellmap, unsigned* keyA, unsigned* idxA, unsigned* keyB, unsigned* idxB,
     int* __restrict__ pillar_start, int* __restrict__ pillar_cell, int* __restrict__ npillars,
-    int* __restrict__ nvalid_out, int ncell, int max_voxels, int npass, int bits_rt) {
+    int* __restrict__ nvalid_out, int ncell, int max_voxels, int npass, int bits_rt,
+    const float* __restrict__ pts, float* __restrict__ pts_sorted, int F) {
     const int bits = (BITS > 0) ? BITS : bits_rt;
     __shared__ int s_tot[VWAVES];
     __shared__ int s_carry;
     __shared__ int s_break;
     __shared__ int s_tmp[VWAVES];
     __shared__ int s_hist[256 * VWAVES];
-    __shared__ unsigned s_sort[2 * VL_CAP];
+    constexpr int CAP = VT * PPT;                    // points of a frame on the register / LDS path
+    constexpr bool TABLES = (PPT == 16);             // cell tables fit beside the sort space
+    __shared__ unsigned s_sort[2 * VL_CAP];          // 128 KB: PPT 16: [sort | cell tables], PPT 32: sort
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
     __syncthreads();
 
     // ---- fast path: a frame of up to VL_CAP points is processed out of registers and LDS.  Every thread
-    // owns VL_PPT consecutive points (all of its loads are issued at once: one memory round trip per phase
+    // owns PPT consecutive points (all of its loads are issued at once: one memory round trip per phase
     // instead of one per 1024 points), pillar ids / compaction offsets come from one block-wide scan each,
     // and the (pillar id, point index) pairs are packed into one 32-bit word and radix-sorted in LDS. ----
     int ib = 1;
@@ -146,16 +152,16 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
 #define V_STAMP() {}
 #endif
     V_STAMP()
-    if (n <= VL_CAP && npass * bits + ib <= 32 && (first != nullptr || ncell <= VL_CAP)) {
-        const int ppt = (n + VT - 1) / VT;      // <= VL_PPT
+    if (n <= CAP && npass * bits + ib <= 32 && (first != nullptr || (TABLES && ncell <= VL_CAP))) {
+        const int ppt = (n + VT - 1) / VT;      // <= PPT
         const int i0 = tid * ppt;
-        int c[VL_PPT];
+        int c[PPT];
 #pragma unroll
-        for (int k = 0; k < VL_PPT; ++k) c[k] = (k < ppt && i0 + k < n) ? fcell[i0 + k] : -1;
-        int f[VL_PPT];
+        for (int k = 0; k < PPT; ++k) c[k] = (k < ppt && i0 + k < n) ? fcell[i0 + k] : -1;
+        int f[PPT];
         if (first != nullptr) {
 #pragma unroll
-            for (int k = 0; k < VL_PPT; ++k) f[k] = (c[k] >= 0) ? ffirst[c[k]] : -1;
+            for (int k = 0; k < PPT; ++k) f[k] = (c[k] >= 0) ? ffirst[c[k]] : -1;
         } else {
             // first point index of every cell by LDS atomics (the sort buffers are not in use yet): no global
             // atomics, whose same-address traffic on crowded cells serialises across the chip
@@ -165,23 +171,23 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
             for (int e = tid; e < ncell; e += VT) s_first[e] = 0x7fffffff;
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < VL_PPT; ++k) if (c[k] >= 0) atomicMin(&s_first[c[k]], i0 + k);
+            for (int k = 0; k < PPT; ++k) if (c[k] >= 0) atomicMin(&s_first[c[k]], i0 + k);
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < VL_PPT; ++k) f[k] = (c[k] >= 0) ? s_first[c[k]] : -1;
+            for (int k = 0; k < PPT; ++k) f[k] = (c[k] >= 0) ? s_first[c[k]] : -1;
             __syncthreads();   // s_sort is written below
         }
         V_STAMP()   // 1: cells loaded, first-of-cell known
         int* const s_map = reinterpret_cast<int*>(s_sort) + VL_CAP;   // cell -> pillar id (LDS copy of fmap)
         unsigned flags = 0;
 #pragma unroll
-        for (int k = 0; k < VL_PPT; ++k) if (c[k] >= 0 && f[k] == i0 + k) flags |= 1u << k;
+        for (int k = 0; k < PPT; ++k) if (c[k] >= 0 && f[k] == i0 + k) flags |= 1u << k;
         int totp;
         const int basep = block_excl_scan(__popc(flags), s_tmp, totp);
         {
             int r = 0;
 #pragma unroll
-            for (int k = 0; k < VL_PPT; ++k)
+            for (int k = 0; k < PPT; ++k)
                 if ((flags >> k) & 1u) {
                     const int pid = basep + r++;
                     if (pid < max_voxels) {
@@ -199,28 +205,30 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
         const int ibreak = s_break;
         unsigned vmask = 0;
 #pragma unroll
-        for (int k = 0; k < VL_PPT; ++k) if (c[k] >= 0 && i0 + k < ibreak) vmask |= 1u << k;
-        int key[VL_PPT];
+        for (int k = 0; k < PPT; ++k) if (c[k] >= 0 && i0 + k < ibreak) vmask |= 1u << k;
+        int key[PPT];
 #pragma unroll
-        for (int k = 0; k < VL_PPT; ++k) key[k] = ((vmask >> k) & 1u) ? (first == nullptr ? s_map[c[k]] : fmap[c[k]]) : 0;
+        for (int k = 0; k < PPT; ++k) key[k] = ((vmask >> k) & 1u) ? (first == nullptr ? s_map[c[k]] : fmap[c[k]]) : 0;
         int nv;
         const int basev = block_excl_scan(__popc(vmask), s_tmp, nv);
         {
             int r = 0;
 #pragma unroll
-            for (int k = 0; k < VL_PPT; ++k)
+            for (int k = 0; k < PPT; ++k)
                 if ((vmask >> k) & 1u) s_sort[basev + r++] = ((unsigned)key[k] << ib) | (unsigned)(i0 + k);
         }
         __syncthreads();
         V_STAMP()   // 3: keys fetched, compaction done
         // stable LSD radix sort of the packed words by pillar id, LDS to LDS
-        unsigned* sk = s_sort;
-        unsigned* dk = s_sort + VL_CAP;
+        // in place: a pass holds every element in registers between its read and its scatter (barriers in
+        // between), so source and destination are the same buffer
+        unsigned* const sk = s_sort;
+        unsigned* const dk = s_sort;
         const int NB = 1 << bits;
         const unsigned dmask = (unsigned)NB - 1u;
         const int chunk = ((nv + VWAVES * 64 - 1) / (VWAVES * 64)) * 64;
         const int wbeg = min(wave * chunk, nv), wend = min(wbeg + chunk, nv);
-        // A wave sorts its contiguous chunk (<= VL_PPT steps of 64 elements, held in registers for the pass).
+        // A wave sorts its contiguous chunk (<= PPT steps of 64 elements, held in registers for the pass).
         // Histogram step: the lanes that share a digit find each other by digit-bit ballots; each reads the
         // wave's running count of that digit (= how many earlier elements of the chunk carry it) and one of
         // them adds the group size -- conflict-free LDS operations that execute in issue order, so the 16
@@ -229,16 +237,16 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
         for (int pass = 0; pass < npass; ++pass) {
             const int shift = ib + pass * bits;
             for (int e = tid; e < NB * VWAVES; e += VT) s_hist[e] = 0;
-            unsigned ev[VL_PPT];
+            unsigned ev[PPT];
 #pragma unroll
-            for (int t = 0; t < VL_PPT; ++t) {
+            for (int t = 0; t < PPT; ++t) {
                 const int j = wbeg + t * 64 + lane;
                 ev[t] = (j < wend) ? sk[j] : 0u;
             }
             __syncthreads();
-            int rank[VL_PPT];
+            int rank[PPT];
 #pragma unroll
-            for (int t = 0; t < VL_PPT; ++t) {
+            for (int t = 0; t < PPT; ++t) {
                 rank[t] = 0;
                 if (wbeg + t * 64 < wend) {                     // wave-uniform
                     const bool act = wbeg + t * 64 + lane < wend;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
             }
             __syncthreads();
 #pragma unroll
-            for (int t = 0; t < VL_PPT; ++t) {
+            for (int t = 0; t < PPT; ++t) {
                 if (wbeg + t * 64 + lane < wend) {
                     const unsigned d = (ev[t] >> shift) & dmask;
                     dk[s_hist[wave * NB + d] + rank[t]] = ev[t];
@@ -294,17 +302,49 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
             }
             __syncthreads();
             V_STAMP()   // 4, 5: sort passes
-            unsigned* t = sk; sk = dk; dk = t;
         }
         // sorted point indices + CSR row starts
         unsigned* fin = ((npass & 1) ? idxB : idxA) + n0;     // the buffer the host reads (voxel_sort_passes)
         int* ps = pillar_start + (size_t)b * (max_voxels + 1);
         const unsigned imask = (1u << ib) - 1u;
-        for (int j = tid; j < nv; j += VT) {
-            const unsigned v = sk[j];
-            fin[j] = v & imask;
-            const unsigned k = v >> ib;
-            if (j == 0 || (sk[j - 1] >> ib) != k) ps[k] = j;
+        // pillar-sorted copy of the points (the CSR payload the PFN streams with contiguous loads): one gather
+        // per point here, inside the one workgroup -- one XCD's L2 -- that owns the frame, instead of one per
+        // point in every PFN wave that touches the line
+        const float* fpts = pts + (size_t)n0 * F;
+        float* fsorted = pts_sorted + (size_t)n0 * F;
+        // (PPT elements per thread, all gathers of a thread issued before the first store: one memory round trip)
+        unsigned srcs[PPT];
+#pragma unroll
+        for (int t = 0; t < PPT; ++t) {
+            const int j = tid + t * VT;
+            srcs[t] = 0u;
+            if (j < nv) {
+                const unsigned v = sk[j];
+                srcs[t] = v & imask;
+                fin[j] = srcs[t];
+                const unsigned k = v >> ib;
+                if (j == 0 || (sk[j - 1] >> ib) != k) ps[k] = j;
+            }
+        }
+        if (F == 4) {
+            float4 pv[PPT];
+#pragma unroll
+            for (int t = 0; t < PPT; ++t) if (tid + t * VT < nv) pv[t] = reinterpret_cast<const float4*>(fpts)[srcs[t]];
+#pragma unroll
+            for (int t = 0; t < PPT; ++t) if (tid + t * VT < nv) reinterpret_cast<float4*>(fsorted)[tid + t * VT] = pv[t];
+        } else {
+            float px[PPT], py[PPT], pz[PPT];
+#pragma unroll
+            for (int t = 0; t < PPT; ++t)
+                if (tid + t * VT < nv) {
+                    px[t] = fpts[(size_t)srcs[t] * 3 + 0]; py[t] = fpts[(size_t)srcs[t] * 3 + 1]; pz[t] = fpts[(size_t)srcs[t] * 3 + 2];
+                }
+#pragma unroll
+            for (int t = 0; t < PPT; ++t)
+                if (tid + t * VT < nv) {
+                    const size_t j = (size_t)(tid + t * VT);
+                    fsorted[j * 3 + 0] = px[t]; fsorted[j * 3 + 1] = py[t]; fsorted[j * 3 + 2] = pz[t];
+                }
         }
         if (tid == 0) {
             ps[P] = nv;
@@ -447,9 +487,20 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
 
     // ---- D: CSR row starts from the key boundaries ----
     int* ps = pillar_start + (size_t)b * (max_voxels + 1);
-    for (int j = tid; j < nv; j += VT) {
-        const unsigned k = sk[j];
-        if (j == 0 || sk[j - 1] != k) ps[k] = j;
+    {
+        const float* fpts = pts + (size_t)n0 * F;
+        float* fsorted = pts_sorted + (size_t)n0 * F;
+        for (int j = tid; j < nv; j += VT) {
+            const unsigned k = sk[j];
+            if (j == 0 || sk[j - 1] != k) ps[k] = j;
+            const unsigned src = sv[j];
+            if (F == 4) {
+                reinterpret_cast<float4*>(fsorted)[j] = reinterpret_cast<const float4*>(fpts)[src];
+            } else {
+                const float x = fpts[(size_t)src * 3 + 0], y = fpts[(size_t)src * 3 + 1], z = fpts[(size_t)src * 3 + 2];
+                fsorted[(size_t)j * 3 + 0] = x; fsorted[(size_t)j * 3 + 1] = y; fsorted[(size_t)j * 3 + 2] = z;
+            }
+        }
     }
     if (tid == 0) {
         ps[P] = nv;
@@ -459,7 +510,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
 }
 
 // compat: the reference's padded outputs for ONE frame (load_data.py:757-771)
-__global__ __launch_bounds__(64) void k_voxel_expand(const float* __restrict__ pts,
+__global__ __launch_bounds__(64) void k_voxel_expand(const float* __restrict__ pts_sorted,
                                                      const int* __restrict__ offsets,
                                                      const unsigned* __restrict__ sorted_idx,
                                                      const int* __restrict__ pillar_start,
@@ -473,11 +524,11 @@ __global__ __launch_bounds__(64) void k_voxel_expand(const float* __restrict__ p
     const int* ps = pillar_start + (size_t)frame * (max_voxels + 1);
     const int start = ps[p];
     const int cnt = min(ps[p + 1] - start, T);
-    const unsigned* sidx = sorted_idx + n0 + start;
+    (void)sorted_idx;
     for (int e = threadIdx.x; e < T * F; e += 64) {
         const int s = e / F, f = e - s * F;
         float v = 0.f;
-        if (s < cnt) v = pts[(size_t)(n0 + sidx[s]) * F + f];
+        if (s < cnt) v = pts_sorted[(size_t)(n0 + start + s) * F + f];
         voxels[((size_t)p * T) * F + e] = v;
     }
     if (threadIdx.x == 0) {
@@ -514,34 +565,41 @@ void launch_cell_first(const float* pts, const int* offsets, int batch, int max_
                        int* cell, int* first, int* cellmap, hipStream_t s) {
     if (batch <= 0) return;
     dim3 grid(max_n > 0 ? (max_n + 255) / 256 : 1, batch);   // at least one block per frame: it clears the cell map
-    hipLaunchKernelGGL(k_cell_first, grid, dim3(256), 0, s, pts, offsets, F, g, cell, first, cellmap);
+    PP_LAUNCH("k_cell_first", k_cell_first, grid, dim3(256), 0, s, pts, offsets, F, g, cell, first, cellmap);
 }
 
 void launch_voxel_frame(const int* offsets, const int* cell, const int* first, int* cellmap, unsigned* keyA,
                         unsigned* idxA, unsigned* keyB, unsigned* idxB, int* pillar_start, int* pillar_cell,
-                        int* npillars, int* nvalid, int batch, int ncell, int max_voxels, hipStream_t s) {
+                        int* npillars, int* nvalid, int batch, int max_n, int ncell, int max_voxels, const float* pts,
+                        float* pts_sorted, int F, hipStream_t s) {
     if (batch <= 0) return;
     int kb = 1;
     while ((1 << kb) < max_voxels) ++kb;
     const int npass = (kb + 7) / 8;
     const int bits = (kb + npass - 1) / npass;
-    if (bits == 7)   // 8193..16384 pillars (the shipped configuration): unrolled digit loops
-        hipLaunchKernelGGL(k_voxel_frame<7>, dim3(batch), dim3(VT), 0, s, offsets, cell, first, cellmap, keyA, idxA, keyB,
-                           idxB, pillar_start, pillar_cell, npillars, nvalid, ncell, max_voxels, npass, bits);
-    else
-        hipLaunchKernelGGL(k_voxel_frame<0>, dim3(batch), dim3(VT), 0, s, offsets, cell, first, cellmap, keyA, idxA, keyB,
-                           idxB, pillar_start, pillar_cell, npillars, nvalid, ncell, max_voxels, npass, bits);
+    // frames of more than 16 384 points (KITTI-sized clouds) run the 32-points-per-thread instantiation
+    const bool big = max_n > VL_CAP;
+#define VOX_LAUNCH(B_, P_)                                                                                            \
+    PP_LAUNCH("k_voxel_frame", (k_voxel_frame<B_, P_>), dim3(batch), dim3(VT), 0, s, offsets, cell, first, cellmap, keyA, \
+              idxA, keyB, idxB, pillar_start, pillar_cell, npillars, nvalid, ncell, max_voxels, npass, bits, pts,      \
+              pts_sorted, F)
+    if (bits == 7) {   // 8193..16384 pillars (the shipped configuration): unrolled digit loops
+        if (big) VOX_LAUNCH(7, 32); else VOX_LAUNCH(7, 16);
+    } else {
+        if (big) VOX_LAUNCH(0, 32); else VOX_LAUNCH(0, 16);
+    }
+#undef VOX_LAUNCH
 }
 
 void launch_voxel_expand(const float* pts, const int* offsets, const unsigned* sorted_idx, const int* pillar_start,
                          const int* pillar_cell, const int* npillars, int frame, int F, int T, int max_voxels,
                          int ny, int nx, float* voxels, int* coors, int* num_points, hipStream_t s) {
-    hipLaunchKernelGGL(k_voxel_expand, dim3(max_voxels), dim3(64), 0, s, pts, offsets, sorted_idx, pillar_start,
+    PP_LAUNCH("k_voxel_expand", k_voxel_expand, dim3(max_voxels), dim3(64), 0, s, pts, offsets, sorted_idx, pillar_start,
                        pillar_cell, npillars, frame, F, T, max_voxels, ny, nx, voxels, coors, num_points);
 }
 
 void launch_build_cellmap(const int* coors4, int64_t P, int ncell, int ny, int nx, int* cellmap, hipStream_t s) {
     if (P <= 0) return;
-    hipLaunchKernelGGL(k_build_cellmap, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, coors4, P, ncell, ny,
+    PP_LAUNCH("k_build_cellmap", k_build_cellmap, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, coors4, P, ncell, ny,
                        nx, cellmap);
 }

@@ -34,6 +34,33 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+class Staging:
+    """A page-locked host buffer (pp_host_alloc) viewed as a flat float32 numpy array."""
+
+    def __init__(self, lib, nbytes):
+        self._lib = lib
+        p = ctypes.c_void_p()
+        st = lib.pp_host_alloc(ctypes.c_int64(nbytes), ctypes.byref(p))
+        if st != 0:
+            raise RuntimeError(f"pp_host_alloc({nbytes}) failed ({_STATUS.get(st, st)})")
+        self._p = p
+        self.array = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), shape=(max(nbytes // 4, 1),))
+        self.points = None
+        self.offsets = None
+
+    def close(self):
+        if self._p:
+            self.array = self.points = None
+            self._lib.pp_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """config: reference-schema dict (or a config.Derived).  max_batch /
     max_points_per_frame size the device workspaces."""
@@ -60,6 +87,8 @@ class Engine:
         thr = d.anchor_area_threshold
         c.anchor_area_threshold = float(thr) if thr is not None else -1.0
         c.max_batch, c.max_points_per_frame = self.max_batch, self.max_points_per_frame
+        c.use_direction_classifier = 1 if d.use_direction_classifier else 0
+        c.with_distance = 1 if d.with_distance else 0
         h = ctypes.c_void_p()
         st = self._lib.pp_create(ctypes.byref(c), int(device), ctypes.byref(h))
         if st != 0:
@@ -73,6 +102,10 @@ class Engine:
         self.weights_loaded = False
         if weights is not None:
             self.load_weights(weights)
+
+    @staticmethod
+    def det_dtype():
+        return DET_DTYPE
 
     # ---- plumbing ----
     def _check(self, st, what):
@@ -137,13 +170,15 @@ class Engine:
         H, W, k = d.head_h, d.head_w, d.num_anchor_per_loc
         box = np.empty((batch, H, W, k * 7), dtype=np.float32)
         cls = np.empty((batch, H, W, k * d.num_class), dtype=np.float32)
-        dr = np.empty((batch, H, W, k * 2), dtype=np.float32)
+        dr = np.empty((batch, H, W, k * 2), dtype=np.float32) if d.use_direction_classifier else None
         feat = np.empty((P, d.pfn_filters), dtype=np.float32) if want_features else None
         canvas = np.empty((batch, d.ny, d.nx, d.pfn_filters), dtype=np.float32) if want_canvas else None
         self._check(self._lib.pp_forward_voxels(self._h, _ptr(voxels), _ptr(num_points), _ptr(coors4),
                                                 ctypes.c_int64(P), int(batch), _ptr(box), _ptr(cls), _ptr(dr),
                                                 _ptr(feat), _ptr(canvas)), "pp_forward_voxels")
-        out = {"box_preds": box, "cls_preds": cls, "dir_cls_preds": dr}
+        out = {"box_preds": box, "cls_preds": cls}
+        if dr is not None:             # model/voxelnet.py:714: the key exists only with the direction head
+            out["dir_cls_preds"] = dr
         if want_features:
             out["pillar_features"] = feat
         if want_canvas:
@@ -159,7 +194,8 @@ class Engine:
         m = np.ascontiguousarray(anchors_mask, dtype=np.uint8).reshape(batch, -1)
         if m.shape[1] != self.anchors.shape[0]:
             raise ValueError(f"anchors_mask must be [batch,{self.anchors.shape[0]}]")
-        self._check(self._lib.pp_predict(self._h, _ptr(_f32(box_preds)), _ptr(_f32(cls_preds)), _ptr(_f32(dir_cls_preds)),
+        dirp = _f32(dir_cls_preds) if self.d.use_direction_classifier else None
+        self._check(self._lib.pp_predict(self._h, _ptr(_f32(box_preds)), _ptr(_f32(cls_preds)), _ptr(dirp),
                                          _ptr(m), _ptr(_f32(rect).reshape(batch, 16)), _ptr(_f32(trv2c).reshape(batch, 16)),
                                          int(batch), _ptr(dets), _ptr(n)), "pp_predict")
         return dets, n
@@ -180,17 +216,41 @@ class Engine:
         pts, offs = self._pack(frames, self.d.num_point_features)
         self._check(self._lib.pp_upload_points(self._h, _ptr(pts), _ptr(offs), len(frames)), "pp_upload_points")
         if rect is not None:
-            B = len(frames)
-            self._check(self._lib.pp_set_calib(self._h, _ptr(_f32(rect).reshape(B, 16)), _ptr(_f32(trv2c).reshape(B, 16)), B),
-                        "pp_set_calib")
-        self._batch = len(frames)
+            self.set_calib(rect, trv2c, len(frames))
 
-    def upload_device(self, dev_ptr, offsets):
-        """dev_ptr: integer device address of concatenated [sum N, F] float32 points."""
+    def set_calib(self, rect, trv2c, batch):
+        self._check(self._lib.pp_set_calib(self._h, _ptr(_f32(rect).reshape(batch, 16)),
+                                           _ptr(_f32(trv2c).reshape(batch, 16)), batch), "pp_set_calib")
+
+    def staging(self, frames):
+        """Packs frames into a page-locked staging buffer (pp_host_alloc) for upload_async.  Returns a
+        Staging whose `.points` / `.offsets` may be refilled in place between uses."""
+        pts, offs = self._pack(frames, self.d.num_point_features)
+        st = Staging(self._lib, max(pts.nbytes, 4))
+        st.points = st.array[:pts.size].reshape(pts.shape)
+        st.points[...] = pts
+        st.offsets = offs
+        return st
+
+    def upload_async(self, staging):
+        """Queues the host-to-device copy of a Staging on the engine's stream and returns at once; the staging
+        buffer must not be rewritten before the sync() that follows the detect_async() consuming it."""
+        self._check(self._lib.pp_upload_points_async(self._h, _ptr(staging.points), _ptr(staging.offsets),
+                                                     staging.offsets.shape[0] - 1), "pp_upload_points_async")
+
+    def upload_device(self, dev_ptr, offsets, producer_stream=None):
+        """dev_ptr: integer device address of concatenated [sum N, F] float32 points.  producer_stream: integer
+        hipStream_t handle the points were written on (e.g. torch.cuda.current_stream().cuda_stream), or None
+        if that work has already completed."""
         offs = _i32(offsets)
-        self._check(self._lib.pp_upload_points_device(self._h, ctypes.c_void_p(int(dev_ptr)), _ptr(offs), offs.shape[0] - 1),
-                    "pp_upload_points_device")
-        self._batch = offs.shape[0] - 1
+        ps = ctypes.c_void_p(int(producer_stream)) if producer_stream else None
+        self._check(self._lib.pp_upload_points_device(self._h, ctypes.c_void_p(int(dev_ptr)), _ptr(offs),
+                                                      offs.shape[0] - 1, ps), "pp_upload_points_device")
+
+    def _batches(self):
+        up, res = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._check(self._lib.pp_current_batch(self._h, ctypes.byref(up), ctypes.byref(res)), "pp_current_batch")
+        return up.value, res.value
 
     def detect_async(self):
         self._check(self._lib.pp_detect_async(self._h), "pp_detect_async")
@@ -198,10 +258,14 @@ class Engine:
     def sync(self):
         self._check(self._lib.pp_sync(self._h), "pp_sync")
 
-    def detections(self):
-        B, post = self._batch, self.d.nms_post_max_size
-        dets = np.zeros((B, post), dtype=DET_DTYPE)
-        n = np.zeros((B,), dtype=np.int32)
+    def detections(self, out=None):
+        """Results of the last detect_async (waits for it).  out: optional (dets, n) arrays to fill."""
+        B, post = self._batches()[1], self.d.nms_post_max_size
+        if out is None:
+            out = (np.zeros((max(B, 1), post), dtype=DET_DTYPE), np.zeros((max(B, 1),), dtype=np.int32))
+        dets, n = out
+        if dets.shape[0] < B or n.shape[0] < B:
+            raise ValueError("detections(out=...): arrays smaller than the batch")
         self._check(self._lib.pp_get_detections(self._h, _ptr(dets), _ptr(n)), "pp_get_detections")
         return dets, n
 
@@ -212,7 +276,7 @@ class Engine:
         return self.detections()
 
     def intermediates(self, canvas=False):
-        d, B = self.d, self._batch
+        d, B = self.d, max(self._batches()[1], 1)
         H, W, k = d.head_h, d.head_w, d.num_anchor_per_loc
         out = {
             "n_pillars": np.zeros((B,), np.int32),
@@ -220,8 +284,8 @@ class Engine:
             "num_points": np.zeros((B, d.max_voxels), np.int32),
             "anchors_mask": np.zeros((B, self.anchors.shape[0]), np.uint8),
             "box_preds": np.zeros((B, H, W, k * 7), np.float32),
-            "cls_preds": np.zeros((B, H, W, k), np.float32),
-            "dir_cls_preds": np.zeros((B, H, W, k * 2), np.float32),
+            "cls_preds": np.zeros((B, H, W, k * d.num_class), np.float32),
+            "dir_cls_preds": np.zeros((B, H, W, k * 2), np.float32) if d.use_direction_classifier else None,
         }
         cv = np.zeros((B, d.ny, d.nx, d.pfn_filters), np.float32) if canvas else None
         self._check(self._lib.pp_fetch_intermediates(
@@ -230,6 +294,8 @@ class Engine:
             "pp_fetch_intermediates")
         if canvas:
             out["canvas"] = cv
+        if out["dir_cls_preds"] is None:
+            del out["dir_cls_preds"]
         return out
 
     # ---- measurement ----

@@ -4,8 +4,8 @@ Mirror of load_data.py:695-771: `points_to_voxel(points, voxel_size,
 coors_range, max_points, reverse_index, max_voxels) -> (voxels, coordinates,
 num_points_per_voxel)`.  The HIP voxeliser (csrc/voxelize.hip) reproduces the
 sequential first-appearance / arrival-order / break semantics bit for bit.
-Only `reverse_index=True` (the value the reference passes, load_data.py:2966)
-is built; anything else raises, as an unsupported flag should.
+`reverse_index=True` is what the reference passes (load_data.py:2966); with False
+(_points_to_voxel_kernel, load_data.py:643-692) the same pillars come back with (x, y, z) columns.
 """
 import numpy as np
 
@@ -49,9 +49,6 @@ def _engine_for(voxel_size, coors_range, max_points, max_voxels, num_features, n
 
 
 def points_to_voxel(points, voxel_size, coors_range, max_points, reverse_index, max_voxels):
-    if not reverse_index:
-        raise NotImplementedError("reverse_index=False is never used by the reference's pipeline "
-                                  "(load_data.py:2966 passes True) and is not built")
     points = np.ascontiguousarray(points, dtype=np.float32)
     if points.ndim != 2 or points.shape[1] < 3:
         raise ValueError("points must be [N, >=3]")
@@ -62,4 +59,9 @@ def points_to_voxel(points, voxel_size, coors_range, max_points, reverse_index, 
         coors_range = np.array(coors_range, dtype=points.dtype)
     eng = _engine_for(np.asarray(voxel_size, dtype=np.float64), np.asarray(coors_range, dtype=np.float64),
                       max_points, max_voxels, points.shape[1], points.shape[0])
-    return eng.points_to_voxel(points)
+    voxels, coors, num = eng.points_to_voxel(points)
+    if not reverse_index:
+        # _points_to_voxel_kernel (load_data.py:643-692) runs the same scan -- same cells, same first-appearance
+        # pillar order, same break -- and only stores the cell as (x, y, z) instead of (z, y, x)
+        coors = np.ascontiguousarray(coors[:, ::-1])
+    return voxels, coors, num

@@ -54,8 +54,8 @@ class VoxelNet:
         rect, trv2c = _np(example[3]), _np(example[4])
         mask, img_idx = _np(example[7]), _np(example[8])
         batch = int(_np(example[6]).shape[0])
-        dets, n = self.engine.predict(_np(preds_dict["box_preds"]), _np(preds_dict["cls_preds"]),
-                                      _np(preds_dict["dir_cls_preds"]), mask, rect, trv2c)
+        dirp = _np(preds_dict["dir_cls_preds"]) if self.d.use_direction_classifier else None
+        dets, n = self.engine.predict(_np(preds_dict["box_preds"]), _np(preds_dict["cls_preds"]), dirp, mask, rect, trv2c)
         return [self._to_dict(dets[b], int(n[b]), img_idx[b]) for b in range(batch)]
 
     def detect(self, frames, rect=None, trv2c=None, image_idx=None):

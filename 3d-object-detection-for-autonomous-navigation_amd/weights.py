@@ -33,7 +33,8 @@ def layer_table(d):
     cc = d.concat_channels
     layers.append(("head", "rpn/conv_box", {"cin": cc, "cout": d.num_anchor_per_loc * 7}))
     layers.append(("head", "rpn/conv_cls", {"cin": cc, "cout": d.num_anchor_per_loc * d.num_class}))
-    layers.append(("head", "rpn/conv_dir_cls", {"cin": cc, "cout": d.num_anchor_per_loc * 2}))
+    if getattr(d, "use_direction_classifier", True):   # model/voxelnet.py:690
+        layers.append(("head", "rpn/conv_dir_cls", {"cin": cc, "cout": d.num_anchor_per_loc * 2}))
     return layers
 
 

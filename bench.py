@@ -4,20 +4,30 @@
     python bench.py --gpus N --steps K --warmup W
 (for N > 1 the driver launches this under torch.distributed.run, one rank per GPU.)
 
-A "step" is one pass of the whole hot path (voxelise -> PFN + scatter -> anchor
-mask -> backbone + heads -> top-k / decode / NMS -> detections copied to pinned
-host memory) over one batch of B = 64 frames whose raw points are already
-resident in HBM when the timed region starts (BASELINE.json configs[1]; the
-shipped reference config, SURVEY "cfg-A").  Frames are independent, so with N
-GPUs every rank processes its own 64 frames (weak scaling, no collective on the
-data path); the timed region is bracketed by a barrier + device sync and the MAX
-over ranks is taken.
+A "step" is one pass of the whole hot path over one batch of B = 64 frames
+(BASELINE.json configs[1]; the shipped reference config, SURVEY "cfg-A"): the
+host-to-device copy of the batch's raw points from a page-locked staging buffer
+(a DIFFERENT batch every step: a pool of distinct synthetic batches is cycled,
+SURVEY section 8d's protocol and train.py:748's per-frame hand-over) -> voxelise ->
+PFN + scatter -> anchor mask -> backbone + heads -> top-k / decode / NMS ->
+detections copied to pinned host memory and read by the host.  `--inflight`
+engine handles (own stream + workspaces) take turns, so the copy of one batch
+overlaps the kernels of the others; a handle is synchronised and its detections
+are fetched before it is given its next batch.  Frames are independent, so with N
+GPUs every rank processes its own frames (weak scaling, no collective on the data
+path); the timed region is bracketed by a barrier + device sync and the MAX over
+ranks is taken.  `detail.resident_fps` is the same loop without the per-step
+upload (points resident in HBM).
 
 The JSON line also carries
-  roofline      the dominant kernel (largest share of GPU time), its average
-                launch duration measured with HIP events on the engine's own
-                stream in this process, and algorithmic flops (or bytes) per
-                launch / that duration against the gfx950 peak;
+  roofline      the dominant kernel (largest share of GPU time with ONE batch in
+                flight), its average launch duration measured in this process
+                with a HIP start/stop event pair carried by each launch
+                (hipExtLaunchKernelGGL: the kernel's own execution interval, what
+                rocprofv3's kernel trace reports), and algorithmic flops (or
+                bytes) per launch / that duration against the gfx950 peak
+                (`frac`); `frac_overlapped` is the same with --inflight batches
+                sharing the chip;
   cpu_baseline  the CPU oracle (a faithful restatement of the reference's
                 numpy/TF path: C voxeliser + numpy PFN + torch-CPU backbone +
                 numpy predict) timed on this host on a bounded sample, rank 0,
@@ -37,8 +47,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
-BF16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16, 32 cyc/SIMD)
-SPLIT_TERMS = 6                # bf16 products per float32 product in the split-precision kernels
+BF16_MFMA_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense 16-bit MFMA (v_mfma_f32_32x32x16_f16 / _bf16, 32 cyc/SIMD)
+# 16-bit products per float32 product in the split-precision kernels: 3 (two float16 pieces per operand: hi*hi,
+# hi*mid, mid*hi; the library's default build) or 6 (PP_SPLIT_MODE=0 build: three bfloat16 pieces)
+SPLIT_TERMS = 6 if "bf16x3" in os.environ.get("PP_HIP_LIB", "") else 3
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -96,9 +108,18 @@ def stage_bytes(d, batch, n_points, n_pillars):
         "k_cell_first": batch * (4 * F * n_points + 4 * n_points),
         "k_voxel_frame": batch * (4 * n_points * 2 + 16 * n_pillars + 4 * n_points),
         "k_pfn_canvas": batch * (4 * F * n_points + 16 * n_pillars + 4 * d.ny * d.nx * C),
-        "anchor_mask": batch * (4 * d.ny * d.nx * d.nz + 4 * d.ny * d.nx + d.num_anchors * 17),
+        "k_occ_rowscan": batch * (4 * d.ny * d.nx * d.nz + 4 * d.ny * d.nx),
+        "k_colscan": batch * (8 * d.ny * d.nx),
+        "k_anchor_lookup": batch * (4 * d.ny * d.nx + d.num_anchors * 17),
         "k_postprocess": batch * (d.num_anchors * 5),
     }
+
+
+def stage_key(sym):
+    """stage_bytes key of a non-GEMM kernel symbol."""
+    if sym.startswith("k_pfn_canvas"):
+        return "k_pfn_canvas"
+    return sym.split("(")[0].split("<")[0]
 
 
 def cpu_baseline(pp, d, weights, frames, calib, budget_s=20.0):
@@ -132,28 +153,215 @@ def is_split_kernel(sym):
     return False
 
 
+class Feeder:
+    """The evaluate loop body of train.py:689-786 for `len(engines)` batches in flight: step i gives engine
+    i % n the staged batch i % pool (host-to-device copy + the whole path, all asynchronous); before an engine
+    gets its next batch the host waits for its previous one and fetches the detections."""
+
+    def __init__(self, engines, stagings, upload=True):
+        self.engines, self.stagings, self.upload = engines, stagings, upload
+        self.busy = [False] * len(engines)
+        self.i = 0
+        self.n_det = 0          # detections the host has read (checksum of the consumed results)
+        self.n_batches = 0
+        e0 = engines[0]
+        self.out = (np.zeros((e0.max_batch, e0.d.nms_post_max_size), dtype=type(e0).det_dtype()),
+                    np.zeros((e0.max_batch,), dtype=np.int32))
+
+    def _collect(self, k):
+        if self.busy[k]:
+            e = self.engines[k]
+            e.sync()
+            dets, n = e.detections(self.out)
+            self.n_det += int(n[:self.stagings[0].offsets.shape[0] - 1].sum())
+            self.n_batches += 1
+            self.busy[k] = False
+
+    def step(self):
+        k = self.i % len(self.engines)
+        e = self.engines[k]
+        if self.upload:   # on the handle's copy stream, into its other input buffer: runs beside the pass in flight
+            e.upload_async(self.stagings[self.i % len(self.stagings)])
+        self._collect(k)
+        e.detect_async()
+        self.busy[k] = True
+        self.i += 1
+
+    def drain(self):
+        for k in range(len(self.engines)):
+            self._collect(k)
+
+
+def timed_run(feeder, steps, warmup, barrier):
+    for _ in range(warmup):
+        feeder.step()
+    feeder.drain()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        feeder.step()
+    feeder.drain()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def kernel_pass(engines, feeder_factory, steps):
+    """Per-kernel execution times (ms) with the feeder's pattern: {tag: [samples]}."""
+    for e in engines:
+        e.set_profiling(True)
+    samples = {}
+    f = feeder_factory()
+    orig = f._collect
+
+    def collect(k):
+        was = f.busy[k]
+        orig(k)
+        if was:
+            for tag, ms in engines[k].kernel_times():
+                samples.setdefault(tag, []).append(ms)
+    f._collect = collect
+    for _ in range(steps):
+        f.step()
+    f.drain()
+    for e in engines:
+        e.set_profiling(False)
+    return samples
+
+
+def summarise(samples, steps):
+    """{tag: [ms]} -> per-symbol (ms per step, launches per step), per-layer mean ms, dropped-sample count.
+    A launch now and then lands on a stall that is not the kernel's: samples beyond 4x the tag's median are
+    left out of the averages and counted."""
+    agg, per_layer, dropped = {}, {}, 0
+    for tag, ms_list in samples.items():
+        med = float(np.median(ms_list))
+        kept = [m for m in ms_list if m <= 4.0 * med] or ms_list
+        dropped += len(ms_list) - len(kept)
+        mean = sum(kept) / len(kept)
+        sym, _, layer = tag.partition(":")
+        a = agg.setdefault(sym, [0.0, 0])
+        a[0] += mean * len(ms_list)
+        a[1] += len(ms_list)
+        if layer:
+            per_layer[layer] = (mean, sym)
+    kernel_ms = {k: v[0] / steps for k, v in agg.items()}
+    launches = {k: v[1] / steps for k, v in agg.items()}
+    return kernel_ms, launches, per_layer, dropped
+
+
+def kernel_roofs(d, B, n_points, n_pillars, kernel_ms, launches, per_layer, heads_fused):
+    """Every kernel symbol against its roofs: algorithmic bytes / flops per launch over the average launch time."""
+    lf, lb = layer_flops(d, B, heads_fused), layer_bytes(d, B, heads_fused)
+    sb = stage_bytes(d, B, n_points, n_pillars)
+    out = {}
+    for sym, ms in kernel_ms.items():
+        t = ms / launches[sym] * 1e-3
+        mine = [layer for layer, (_, s) in per_layer.items() if s == sym and layer in lf]
+        r = {"avg_launch_ms": ms / launches[sym], "launches_per_step": launches[sym]}
+        if mine:
+            fl = sum(lf[n] for n in mine) / len(mine)
+            by = sum(lb[n] for n in mine) / len(mine)
+            split = is_split_kernel(sym)
+            peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_TERMS if split else F32_MFMA_PEAK_TFLOPS
+            r.update({"algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
+                      "fp32_equivalent_tflops": fl / t / 1e12, "GBps": by / t / 1e9,
+                      "frac_of_mfma_roof": fl / t / 1e12 / peak, "frac_of_hbm_roof": by / t / 1e9 / HBM_PEAK_GBS,
+                      "mfma_roof": (f"16-bit dense {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {SPLIT_TERMS} products per fp32 product"
+                                    if split else "f32 MFMA"), "mfma_peak": peak})
+        else:
+            by = sb.get(stage_key(sym))
+            if by:
+                r.update({"algorithmic_bytes_per_launch": by, "GBps": by / t / 1e9,
+                          "frac_of_hbm_roof": by / t / 1e9 / HBM_PEAK_GBS})
+        out[sym] = r
+    return out
+
+
+def roofline_of(sym, r):
+    """The contract's roofline object for kernel `sym` from its kernel_roofs entry (binding roof = larger fraction)."""
+    fh, fm = r.get("frac_of_hbm_roof", 0.0), r.get("frac_of_mfma_roof", 0.0)
+    if fm > fh:
+        base = {"bound": "mfma", "kernel": sym, "achieved": r["fp32_equivalent_tflops"], "peak": r["mfma_peak"],
+                "unit": "TFLOP/s", "frac": fm, "traffic": None}
+    else:
+        base = {"bound": "hbm", "kernel": sym, "achieved": r.get("GBps", 0.0), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": fh, "traffic": None}
+    base.update({k: v for k, v in r.items() if k != "mfma_peak"})
+    return base
+
+
+def cfgk_leg(pp, local_rank, steps=12):
+    """BASELINE.json configs[2]: KITTI-shaped clouds (20k points, 0.16 m pillars, 496x432 BEV, Pedestrian+Cyclist
+    as two classes), batch 32 on one GPU, same feeder (a different staged batch per step)."""
+    B, N = 32, 20000
+    cfg = pp.config.kitti_shaped_config(B, num_class=2)
+    engines = [pp.Engine(cfg, max_batch=B, max_points_per_frame=N, device=local_rank) for _ in range(2)]
+    d = engines[0].d
+    w = pp.weights.init_weights(d, seed=5)
+    calib = pp.synth.default_calib()
+    pool = 3
+    stagings = [engines[0].staging([pp.synth.kitti_cloud(1000 + j * B + i, N) for i in range(B)]) for j in range(pool)]
+    for e in engines:
+        e.load_weights(w)
+        e.set_calib(np.stack([calib[0]] * B), np.stack([calib[1]] * B), B)
+    sync = lambda: None
+    out = {"workload": f"cfg-K (432x496 BEV, 0.16 m pillars, T=100, C=64, strides [2,2,2], 2 classes), B={B} x {N} pts, "
+                       "upload inside the step"}
+    for nfl in (2, 1):
+        f = Feeder(engines[:nfl], stagings)
+        el = timed_run(f, steps, 3, sync)
+        key = "" if nfl == 2 else "_inflight1"
+        out["fps" + key] = B * steps / el
+        out["ms_per_step" + key] = el / steps * 1e3
+        out["mean_detections_per_frame"] = f.n_det / max(f.n_batches * B, 1)
+    samples = kernel_pass(engines[:1], lambda: Feeder(engines[:1], stagings), 3)
+    kernel_ms, launches, per_layer, dropped = summarise(samples, 3)
+    n_pillars = float(engines[0].intermediates()["n_pillars"].mean())
+    heads_fused = not any(t.endswith(":heads") for t in engines[0].layer_tags())
+    roofs = kernel_roofs(d, B, N, n_pillars, kernel_ms, launches, per_layer, heads_fused)
+    dom = max(kernel_ms, key=kernel_ms.get)
+    out["mean_pillars_per_frame"] = n_pillars
+    out["kernel_ms_per_step_inflight1"] = {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])}
+    out["roofline"] = roofline_of(dom, roofs[dom])
+    out["layer_ms"] = {k: round(v[0], 4) for k, v in per_layer.items()}
+    for s in stagings:
+        s.close()
+    for e in engines:
+        e.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--points", type=int, default=16384)
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=2,
                     help="batches in flight per GPU: each has its own engine handle (stream + workspaces), steps "
-                         "alternate between them so the latency-bound front of one step (voxelise, PFN, NMS) "
-                         "overlaps the MFMA-bound backbone of the other")
+                         "take turns so the upload and the latency-bound front of one step (voxelise, PFN, NMS) "
+                         "overlap the backbone of the others")
+    ap.add_argument("--pool", type=int, default=4, help="distinct staged batches cycled through (pinned host memory)")
+    ap.add_argument("--plain", action="store_true",
+                    help="warm-up + timed region only (no per-kernel event pass, no latency / cfg-K / CPU legs): the "
+                         "run rocprofv3 wraps for profiles/*_kernel_stats.csv, one regime per file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfgk", action="store_true", help="skip the KITTI-shaped B=32 leg (detail.cfgK)")
     ap.add_argument("--latency-b1", action="store_true", help="(default; kept for older command lines)")
-    ap.add_argument("--no-latency-b1", action="store_true",
-                    help="skip the batch-1 latency leg (40 single-frame detections on a separate engine after the "
-                         "timed region; its small maps run the split-K kernels, so the B=64 kernels' profiler "
-                         "averages are not mixed with it, but voxelise / PFN / post-process launches are)")
+    ap.add_argument("--no-latency-b1", action="store_true", help="skip the batch-1 latency leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = world if world > 1 else 1
+    want_cpu = rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not args.plain
+    if want_cpu:
+        # the checker library of the cpu_baseline leg is built (make, a child process) and loaded now, before
+        # anything in this process has touched the GPU
+        from oracle import c_oracle
+        c_oracle.lib()
     import torch
     dist = None
     comm_dev = f"cuda:{local_rank}"
@@ -175,7 +383,6 @@ def main():
         dist.all_reduce(warm)
         dist.barrier()
         torch.cuda.synchronize()
-    n_gpus = world if world > 1 else 1
 
     import pp_amd as pp
     pp._lib.lib()  # fails loudly if the HIP library is missing
@@ -187,115 +394,83 @@ def main():
     d = eng.d
     weights = pp.weights.init_weights(d, seed=7)
     calib = pp.synth.default_calib()
-    frame_ids = pp.frame_shard.rank_frames(rank, n_gpus, B)     # this rank's frames (weak scaling)
+    pool = max(1, args.pool)
+    frame_ids = pp.frame_shard.rank_frames(rank, n_gpus, B * pool)     # this rank's frames (weak scaling)
     frames = [pp.synth.d435i_cloud(i, N, d.num_point_features) for i in frame_ids]
+    stagings = [eng.staging(frames[j * B:(j + 1) * B]) for j in range(pool)]
     for e in engines:
         e.load_weights(weights)
-        e.upload(frames, np.stack([calib[0]] * B), np.stack([calib[1]] * B))   # points now resident in HBM
+        e.set_calib(np.stack([calib[0]] * B), np.stack([calib[1]] * B), B)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        engines[i % len(engines)].detect_async()
-    for e in engines:
-        e.sync()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        engines[i % len(engines)].detect_async()
-    for e in engines:
-        e.sync()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    feeder = Feeder(engines, stagings)
+    elapsed = timed_run(feeder, args.steps, args.warmup, barrier)
     elapsed = pp.frame_shard.max_over_ranks(elapsed, dist, comm_dev)
     counts = pp.frame_shard.gather_counts(B * args.steps, dist, comm_dev)
     ms_per_step = elapsed / args.steps * 1e3
     fps = sum(counts) / elapsed
-    dets, n_det = eng.detections()
+    mean_det = feeder.n_det / max(feeder.n_batches * B, 1)
     im_np = eng.intermediates()["n_pillars"]
+    info = eng.device_info()
+    line = {
+        "metric": "frames/sec (whole node) + p50 per-frame ms, 16k-pt pillars",
+        "value": fps, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ("f32" if os.environ.get("PP_GEMM_PREC", "")[:1] == "f"
+                  else "f32 (GEMMs on the 16-bit matrix pipe as split operands -- two float16 pieces per value, 3 products, "
+                       "fp32 accumulate: fp32-equivalent results, measured 1.5e-6 max from the fp32 oracle at this shape)"),
+        "data": "synthetic",
+        "config": {"workload": f"cfg-A (shipped d435i pedestrian config, 80x64 BEV, T=50, C=128), "
+                               f"B={B} frames/GPU x {N} pts per step, host-to-device copy of a different staged batch "
+                               f"every step -> raw points -> detections read by the host (BASELINE.json configs[1])",
+                   "batch_per_gpu": B, "points_per_frame": N, "parallelism": f"frame-parallel x{n_gpus}, no collective",
+                   "batches_in_flight_per_gpu": len(engines), "distinct_batches_cycled": pool,
+                   "upload_in_timed_region": True,
+                   "mean_pillars_per_frame": float(im_np.mean()), "mean_detections_per_frame": mean_det,
+                   "device": info["name"], "compute_units": info["compute_units"]},
+    }
+    if args.plain:
+        if rank == 0:
+            print(json.dumps(line))
+        for s_ in stagings:
+            s_.close()
+        for e in engines:
+            e.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    # ---- per-kernel durations (HIP events on each engine's own stream), same process, same
-    # alternating pattern as the timed region so that overlap between in-flight batches is included ----
-    for e in engines:
-        e.set_profiling(True)
-    agg, per_layer = {}, {}
-    prof_steps = max(4, min(12, args.steps))
+    extras = {}
+    # ---- the same loop with the points resident in HBM (no per-step upload): what round 1 reported ----
+    res_steps = min(args.steps, 100)
+    f_res = Feeder(engines, stagings, upload=False)
+    el_res = timed_run(f_res, res_steps, min(args.warmup, 6), barrier)
+    extras["resident_fps"] = n_gpus * B * res_steps / pp.frame_shard.max_over_ranks(el_res, dist, comm_dev)
 
-    samples = {}
-
-    def collect(e):
-        e.sync()
-        for tag, ms in e.kernel_times():
-            samples.setdefault(tag, []).append(ms)
-
-    pending = []
-    for i in range(prof_steps):
-        e = engines[i % len(engines)]
-        if e in pending:
-            collect(e)
-            pending.remove(e)
-        e.detect_async()
-        pending.append(e)
-    for e in pending:
-        collect(e)
-    for e in engines:
-        e.set_profiling(False)
-    # a launch now and then lands on a stall that is not the kernel's (a 25 ms sample was seen once in a
-    # 0.04 ms kernel): samples beyond 4x the tag's median are left out of the averages
-    for tag, ms_list in samples.items():
-        med = float(np.median(ms_list))
-        kept = [m for m in ms_list if m <= 4.0 * med] or ms_list
-        mean = sum(kept) / len(kept)
-        sym, _, layer = tag.partition(":")
-        a = agg.setdefault(sym, [0.0, 0])
-        a[0] += mean * len(ms_list)
-        a[1] += len(ms_list)
-        if layer:
-            per_layer[tag] = [mean * len(ms_list), len(ms_list)]
-    kernel_ms = {k: v[0] / prof_steps for k, v in agg.items()}        # per step
-    launches = {k: v[1] / prof_steps for k, v in agg.items()}
-    dominant = max(kernel_ms, key=kernel_ms.get)
+    # ---- per-kernel execution times: --inflight batches sharing the chip, then ONE batch in flight ----
+    prof_steps = 4 * len(engines)
     heads_fused = not any(t.endswith(":heads") for t in eng.layer_tags())
-    lf = layer_flops(d, B, heads_fused)
-    sb = stage_bytes(d, B, N, float(im_np.mean()))
-    if dominant.startswith(("k_gemm", "k_sep_u", "k_deconv_u", "k_sep_k4", "k_deconv_k4")):
-        # a GEMM layer has two roofs: the matrix pipe (float32 MFMA, or the bf16 pipe at 6 bf16 products per
-        # float32 product for the split-precision kernels) and HBM (input read + output written once); the
-        # one that allows less is the bound that is reported
-        lb = layer_bytes(d, B, heads_fused)
-        mine = [tag.split(":")[1] for tag in per_layer if tag.startswith(dominant + ":")]
-        flops_launch = sum(lf[n] for n in mine) / launches[dominant]
-        bytes_launch = sum(lb[n] for n in mine) / launches[dominant]
-        avg_ms = kernel_ms[dominant] / launches[dominant]
-        split = is_split_kernel(dominant)
-        mfma_peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_TERMS if split else F32_MFMA_PEAK_TFLOPS
-        tf = flops_launch / (avg_ms * 1e-3) / 1e12
-        gbs = bytes_launch / (avg_ms * 1e-3) / 1e9
-        frac_mfma, frac_hbm = tf / mfma_peak, gbs / HBM_PEAK_GBS
-        if frac_hbm >= frac_mfma:
-            roofline = {"bound": "hbm", "kernel": dominant, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": frac_hbm, "traffic": None}
-        else:
-            roofline = {"bound": "mfma", "kernel": dominant, "achieved": tf, "peak": mfma_peak, "unit": "TFLOP/s",
-                        "frac": frac_mfma, "traffic": None}
-        roofline.update({"avg_launch_ms": avg_ms, "launches_per_step": launches[dominant],
-                         "algorithmic_flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": bytes_launch,
-                         "frac_of_mfma_roof": frac_mfma, "frac_of_hbm_roof": frac_hbm,
-                         "mfma_roof": (f"bf16 dense {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {SPLIT_TERMS} products per fp32 product"
-                                       if split else "f32 MFMA"),
-                         "fp32_equivalent_tflops": tf})
-    else:
-        key = dominant.split("(")[0]
-        per_launch = sb.get(key, 0.0) / max(launches[dominant], 1)
-        avg_ms = kernel_ms[dominant] / launches[dominant]
-        achieved = per_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
-                    "launches_per_step": launches[dominant], "algorithmic_bytes_per_launch": per_launch}
+    npil = float(im_np.mean())
+    s_ovl = kernel_pass(engines, lambda: Feeder(engines, stagings), prof_steps)
+    k_ovl, l_ovl, layer_ovl, drop_ovl = summarise(s_ovl, prof_steps)
+    s_iso = kernel_pass(engines[:1], lambda: Feeder(engines[:1], stagings), 8)
+    k_iso, l_iso, layer_iso, drop_iso = summarise(s_iso, 8)
+    roofs_iso = kernel_roofs(d, B, N, npil, k_iso, l_iso, layer_iso, heads_fused)
+    roofs_ovl = kernel_roofs(d, B, N, npil, k_ovl, l_ovl, layer_ovl, heads_fused)
+    dominant = max(k_iso, key=k_iso.get)
+    roofline = roofline_of(dominant, roofs_iso[dominant])
+    if dominant in roofs_ovl:
+        ro = roofline_of(dominant, roofs_ovl[dominant])
+        roofline["frac_overlapped"] = (ro["frac_of_mfma_roof"] if roofline["bound"] == "mfma" else ro["frac_of_hbm_roof"]) \
+            if "frac_of_hbm_roof" in ro else ro["frac"]
+        roofline["avg_launch_ms_overlapped"] = ro["avg_launch_ms"]
+    roofline["timing"] = ("start/stop HIP events carried by each launch (hipExtLaunchKernelGGL), one batch in flight; "
+                          "compare with AverageNs of profiles/r02_inflight1_kernel_stats.csv")
     # HBM traffic of the dominant kernel from the committed PMC passes (profiles/*pmc_traffic.json;
     # rocprofv3 cannot run inside this process), per launch like `achieved`
     try:
@@ -308,127 +483,80 @@ def main():
                 roofline["traffic_source"] = os.path.basename(pmc_files[-1])
     except Exception:
         pass
-    gpu_ms = sum(kernel_ms.values())
-    total_flops = sum(lf.values())
-    extras = {
-        "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
-        "layer_ms": {k: round(v[0] / v[1], 4) for k, v in per_layer.items()},
-        "sum_kernel_ms_per_step": gpu_ms,
-        "backbone_tflops_end_to_end": total_flops / (ms_per_step * 1e-3) / 1e12,
-    }
+    lf = layer_flops(d, B, heads_fused)
+    extras.update({
+        "kernel_ms_per_step_overlapped": {k: round(v, 4) for k, v in sorted(k_ovl.items(), key=lambda kv: -kv[1])},
+        "kernel_ms_per_step_inflight1": {k: round(v, 4) for k, v in sorted(k_iso.items(), key=lambda kv: -kv[1])},
+        "layer_ms_inflight1": {k: round(v[0], 4) for k, v in layer_iso.items()},
+        "sum_kernel_ms_per_step_inflight1": sum(k_iso.values()),
+        "sum_kernel_ms_per_step_overlapped": sum(k_ovl.values()),
+        "kernel_time_over_wall": sum(k_ovl.values()) / ms_per_step,   # > 1: kernels of the in-flight batches overlap
+        "dropped_stall_samples": {"overlapped": drop_ovl, "inflight1": drop_iso},
+        "backbone_tflops_end_to_end": sum(lf.values()) / (ms_per_step * 1e-3) / 1e12,
+        "roofs_inflight1": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()
+                                if kk not in ("mfma_roof", "mfma_peak")} for k, v in roofs_iso.items()},
+    })
 
-    # ---- the same kernels with ONE batch in flight (no overlap between streams): isolated durations and the
-    # dominant kernel's roof fractions without the co-running kernel's share of the chip ----
-    eng.set_profiling(True)
-    iso, iso_layer = {}, {}
-    for _ in range(4):
+    # ---- one batch in flight: throughput and per-step latency distribution (upload included) ----
+    f1 = Feeder(engines[:1], stagings)
+    el1 = timed_run(f1, min(args.steps, 100), 4, barrier)
+    extras["inflight1_fps"] = B * min(args.steps, 100) / el1
+    step_ms = []
+    for i in range(max(5, min(100, args.steps))):
+        t1 = time.perf_counter()
+        eng.upload_async(stagings[i % pool])
         eng.detect_async()
         eng.sync()
-        for tag, ms in eng.kernel_times():
-            sym, _, layer = tag.partition(":")
-            a = iso.setdefault(sym, [0.0, 0])
-            a[0] += ms
-            a[1] += 1
-            if layer:
-                al = iso_layer.setdefault(layer, [0.0, 0, sym])
-                al[0] += ms
-                al[1] += 1
-    eng.set_profiling(False)
-    extras["isolated_avg_launch_ms"] = {k: round(v[0] / v[1], 4) for k, v in sorted(iso.items(), key=lambda kv: -kv[1][0])}
-    # every stage against its roofs, isolated (one batch in flight): algorithmic bytes / flops per launch over the
-    # HIP-event duration; GEMM layers get both roofs, the other kernels the HBM roof
-    lbytes = layer_bytes(d, B, heads_fused)
-    roofs = {}
-    for layer, (tms, cnt, sym) in iso_layer.items():
-        t = tms / cnt * 1e-3
-        if layer in lf:
-            split = is_split_kernel(sym)
-            peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_TERMS if split else F32_MFMA_PEAK_TFLOPS
-            roofs[layer] = {"kernel": sym, "ms": round(t * 1e3, 4), "GBps": round(lbytes[layer] / t / 1e9, 1),
-                            "frac_hbm": round(lbytes[layer] / t / 1e9 / HBM_PEAK_GBS, 3),
-                            "fp32_equiv_TFLOPs": round(lf[layer] / t / 1e12, 1),
-                            "frac_mfma": round(lf[layer] / t / 1e12 / peak, 3)}
-        else:
-            key = sym.split("(")[0]
-            nbytes = sb.get(key)
-            if nbytes:
-                roofs[layer] = {"kernel": sym, "ms": round(t * 1e3, 4), "GBps": round(nbytes / t / 1e9, 1),
-                                "frac_hbm": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 3)}
-    for sym, (tms, cnt) in iso.items():
-        key = sym.split("(")[0]
-        if key in sb and not any(v["kernel"] == sym for v in roofs.values()):
-            t = tms / cnt * 1e-3
-            roofs[key] = {"kernel": sym, "ms": round(t * 1e3, 4), "GBps": round(sb[key] / t / 1e9, 1),
-                          "frac_hbm": round(sb[key] / t / 1e9 / HBM_PEAK_GBS, 3)}
-    extras["isolated_roofs"] = roofs
-    if dominant in iso and "algorithmic_bytes_per_launch" in roofline:
-        t = iso[dominant][0] / iso[dominant][1] * 1e-3
-        extras["isolated_dominant"] = {
-            "kernel": dominant, "avg_launch_ms": t * 1e3,
-            "hbm_GBps": roofline["algorithmic_bytes_per_launch"] / t / 1e9,
-            "frac_of_hbm_roof": roofline["algorithmic_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS}
-        if "algorithmic_flops_per_launch" in roofline:
-            extras["isolated_dominant"]["fp32_equivalent_tflops"] = roofline["algorithmic_flops_per_launch"] / t / 1e12
-
-    extras["kernel_time_over_wall"] = gpu_ms / ms_per_step   # > 1: kernels of the in-flight batches overlap
-
-    # ---- per-step latency distribution of the same workload (synchronous steps) ----
-    step_ms = []
-    for _ in range(max(5, min(100, args.steps))):
-        eng.timer_start()
-        eng.detect_async()
-        step_ms.append(eng.timer_stop())
+        step_ms.append((time.perf_counter() - t1) * 1e3)
     p50_step = float(np.median(step_ms))
 
-    # ---- batch-1 latency (the reference's eval batch size): p50 per frame ----
+    # ---- batch-1 latency (the reference's eval batch size): p50 per frame, upload included ----
     lat = lat95 = None
     if rank == 0 and not args.no_latency_b1:
         e1 = pp.Engine(pp.config.pedestrian_d435i_config(1), max_batch=1, max_points_per_frame=max(N, 4096),
                        device=local_rank, weights=weights)
+        e1.set_calib(calib[0][None], calib[1][None], 1)
+        st1 = [e1.staging(frames[i:i + 1]) for i in range(16)]
         ts = []
         for i in range(108):
-            e1.upload(frames[i % B:i % B + 1], calib[0][None], calib[1][None])
             t1 = time.perf_counter()
+            e1.upload_async(st1[i % 16])
             e1.detect_async()
             e1.sync()
             ts.append((time.perf_counter() - t1) * 1e3)
         lat = float(np.median(ts[8:]))
         lat95 = float(np.percentile(ts[8:], 95))
+        for s_ in st1:
+            s_.close()
         e1.close()
 
+    for s_ in stagings:
+        s_.close()
+    for e in engines:
+        e.close()
+
+    if rank == 0 and n_gpus == 1 and not args.no_cfgk:
+        try:
+            extras["cfgK"] = cfgk_leg(pp, local_rank)
+        except Exception as ex:   # the leg must not take the headline line down with it
+            extras["cfgK"] = {"error": repr(ex)}
+
     cpu = None
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    if want_cpu:
         cpu = cpu_baseline(pp, d, weights, frames[:32], calib)
 
     if rank == 0:
-        info = eng.device_info()
-        line = {
-            "metric": "frames/sec (whole node) + p50 per-frame ms, 16k-pt pillars",
-            "value": fps, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32" if os.environ.get("PP_GEMM_PREC", "")[:1] == "f"
-                      else "f32 (GEMMs on the bf16 matrix pipe as 3-piece split operands, 6 products, fp32 accumulate: "
-                           "fp32-equivalent results, parity 1e-4 with the fp32 oracle)"),
-            "data": "synthetic",
-            "config": {"workload": f"cfg-A (shipped d435i pedestrian config, 80x64 BEV, T=50, C=128), "
-                                   f"B={B} frames/GPU x {N} pts, raw points -> detections end to end "
-                                   f"(BASELINE.json configs[1]); points resident in HBM",
-                       "batch_per_gpu": B, "points_per_frame": N, "parallelism": f"frame-parallel x{n_gpus}, no collective",
-                       "batches_in_flight_per_gpu": len(engines),
-                       "mean_pillars_per_frame": float(im_np.mean()), "mean_detections_per_frame": float(n_det.mean()),
-                       "device": info["name"], "compute_units": info["compute_units"]},
+        line.update({
             "p50_ms_per_step": p50_step,
             "p95_ms_per_step": float(np.percentile(step_ms, 95)),
             "p50_ms_per_frame": p50_step / B,
-            "p50_ms_per_frame_batch1": lat,     # upload excluded: detect_async -> sync, wall clock, 100 frames
+            "p50_ms_per_frame_batch1": lat,     # upload + detect + sync, wall clock, 100 frames
             "p95_ms_per_frame_batch1": lat95,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "detail": extras,
-        }
+        })
         print(json.dumps(line))
-    for e in engines:
-        e.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 1
+#define PP_ABI_VERSION 2
 
 enum pp_status {
     PP_OK = 0,
@@ -56,7 +56,10 @@ typedef struct pp_config {
     int32_t upsample_strides[3];      /* rpn.upsample_strides */
     int32_t num_upsample_filters[3];  /* rpn.num_upsample_filters */
     int32_t num_anchor_per_loc;       /* len(rotations) * len(sizes) */
-    int32_t num_class;                /* model.second.num_class (1) */
+    int32_t num_class;                /* model.second.num_class.  1 in the shipped config; > 1 is an extension the
+                                         reference leaves as a TF stub (model/voxelnet.py:1183-1185): score = max,
+                                         label = argmax over the class logits of an anchor; the fused head row must
+                                         hold num_anchor_per_loc * (7 + num_class + 2) <= 32 columns */
     int32_t nms_pre_max_size;         /* model.second.nms_pre_max_size */
     int32_t nms_post_max_size;        /* model.second.nms_post_max_size */
     float nms_score_threshold;        /* model.second.nms_score_threshold */
@@ -64,6 +67,10 @@ typedef struct pp_config {
     float anchor_area_threshold;      /* eval_input_reader.anchor_area_threshold */
     int32_t max_batch;                /* frames per call the workspaces are sized for */
     int32_t max_points_per_frame;     /* points per frame the workspaces are sized for */
+    int32_t use_direction_classifier; /* model.second.use_direction_classifier (model/voxelnet.py:690,714,1093,1297):
+                                         0 = no conv_dir_cls head, no direction flip */
+    int32_t with_distance;            /* voxel_feature_extractor.with_distance (model/pointpillars.py:185-188): one more
+                                         PFN input feature, the point's Euclidean norm */
 } pp_config;
 
 /* One detection, in NMS keep order (descending score), as VoxelNet.predict
@@ -72,7 +79,7 @@ typedef struct pp_detection {
     double box3d_camera[7]; /* x y z l h w r, float64 as box_lidar_to_camera returns (eval_helper_functions.py:735-740) */
     float box3d_lidar[7];   /* x y z w l h r after the direction flip (model/voxelnet.py:1305-1310) */
     float score;            /* sigmoid(cls) (model/voxelnet.py:1150) */
-    int32_t label;          /* label_preds (always 0: one class) */
+    int32_t label;          /* label_preds: argmax over the class logits (0 when num_class == 1) */
     int32_t dir_label;      /* argmax of the direction head */
     int32_t anchor_index;   /* flat anchor index (y, x, rot) of the source anchor */
     int32_t reserved;
@@ -105,6 +112,9 @@ int pp_finalize_weights(pp_handle h);
 int pp_set_anchors(pp_handle h, const float* anchors, const int32_t* cells, int64_t num_anchors);
 
 /* ---- stage entry points (parity checkpoints) -------------------------- */
+/* These reuse the device buffers of the fused path: after any of them the handle holds no resident frames
+ * and no fused-path results (pp_detect_async / pp_get_detections / pp_fetch_intermediates then return
+ * PP_ERR_STATE until the next upload + detect). */
 
 /* points_to_voxel(points, voxel_size, coors_range, max_points, True, max_voxels)
  * (load_data.py:695-771) for ONE frame of n points [n,F].  Outputs are sized
@@ -142,8 +152,29 @@ int pp_predict(pp_handle h, const float* box_preds, const float* cls_preds, cons
 /* Copies `batch` frames of raw points into the engine's device input buffer.
  * points: concatenated [sum n_b, F]; frame_offsets [batch+1] (row offsets). */
 int pp_upload_points(pp_handle h, const float* points, const int32_t* frame_offsets, int32_t batch);
-/* Same, from a DEVICE pointer `points_dev` (device-to-device copy on the engine's stream). */
-int pp_upload_points_device(pp_handle h, const void* points_dev, const int32_t* frame_offsets, int32_t batch);
+/* Same without waiting: `points_pinned` must be page-locked host memory (pp_host_alloc, or the caller's own
+ * hipHostMalloc / hipHostRegister) and must stay unchanged until the copy has run (pp_sync after the
+ * pp_detect_async that consumes these frames).  frame_offsets is copied before the call returns.
+ * The handle's input is double-buffered and this copy runs on the handle's own copy stream into the buffer
+ * the pass in flight is not reading, so the upload of batch k+1 proceeds beside the kernels of batch k:
+ *     upload_async(k+1); sync + get_detections (batch k); detect_async (batch k+1); ...
+ * pp_detect_async orders itself behind the copy.  This is the double-buffered feed of raw points that replaces
+ * the per-frame host-to-device hand-over of train.py:748. */
+int pp_upload_points_async(pp_handle h, const float* points_pinned, const int32_t* frame_offsets, int32_t batch);
+/* Page-locked host memory for the staging buffers above (stateless; any thread). */
+int pp_host_alloc(int64_t bytes, void** out);
+int pp_host_free(void* p);
+/* Same, from a DEVICE pointer `points_dev` (device-to-device copy on the engine's stream, no wait).
+ * Ordering contract: `producer_stream` is the hipStream_t on which the work that writes `points_dev` was
+ * queued (the engine's stream then waits for an event recorded there), or NULL when that work has already
+ * completed (the caller synchronised).  `points_dev` must stay valid until the engine's stream has passed
+ * the copy. */
+int pp_upload_points_device(pp_handle h, const void* points_dev, const int32_t* frame_offsets, int32_t batch,
+                            void* producer_stream);
+/* Frames currently resident for pp_detect_async (`uploaded`) and frames of the last enqueued
+ * pp_detect_async whose results pp_get_detections returns (`results`); 0 after a stage entry point reused
+ * the buffers.  Either pointer may be NULL. */
+int pp_current_batch(pp_handle h, int32_t* uploaded, int32_t* results);
 /* Calibration for the uploaded frames: rect, trv2c [batch,16]. */
 int pp_set_calib(pp_handle h, const float* rect, const float* trv2c, int32_t batch);
 
@@ -155,7 +186,8 @@ int pp_set_calib(pp_handle h, const float* rect, const float* trv2c, int32_t bat
 int pp_detect_async(pp_handle h);
 /* Waits for the engine's stream. */
 int pp_sync(pp_handle h);
-/* After pp_sync: copies the last results.  dets [batch*nms_post_max_size], n_dets [batch]. */
+/* Copies the results of the last pp_detect_async (waits for the engine's stream first; immediate after
+ * pp_sync).  dets [batch*nms_post_max_size], n_dets [batch].  PP_ERR_STATE when there are none. */
 int pp_get_detections(pp_handle h, pp_detection* dets, int32_t* n_dets);
 /* Convenience: upload + calib + detect + sync + get (the evaluate loop body,
  * train.py:689-786 minus annotation formatting). */

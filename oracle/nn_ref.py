@@ -25,9 +25,10 @@ BN_EPS = 1e-3  # explicit at model/pointpillars.py:109; Keras default for the RP
 # --------------------------------------------------------------------------
 # a5  PillarFeatureNet  (model/pointpillars.py:128-225)
 # --------------------------------------------------------------------------
-def pfn_decorate_np(voxels, num_points, coors, voxel_size, pc_range):
+def pfn_decorate_np(voxels, num_points, coors, voxel_size, pc_range, with_distance=False):
     """Feature decoration + pad mask, fp32 (model/pointpillars.py:143-203).
-    voxels [P,T,F], num_points [P], coors [P,4] (b,z,y,x) -> [P,T,F+5]."""
+    voxels [P,T,F], num_points [P], coors [P,4] (b,z,y,x) -> [P,T,F+5] (+1 with_distance:
+    tf.norm of the raw xyz appended last, model/pointpillars.py:185-188)."""
     voxels = voxels.astype(F32)
     vx, vy = F32(voxel_size[0]), F32(voxel_size[1])
     # Python-float64 arithmetic, then used as an f32 constant (pointpillars.py:121-124)
@@ -38,7 +39,10 @@ def pfn_decorate_np(voxels, num_points, coors, voxel_size, pc_range):
     cx = coors[:, 3].astype(F32)[:, None] * vx + x_off
     cy = coors[:, 2].astype(F32)[:, None] * vy + y_off
     f_center = np.stack([voxels[:, :, 0] - cx, voxels[:, :, 1] - cy], axis=-1)
-    feats = np.concatenate([voxels, f_cluster, f_center], axis=-1)
+    parts = [voxels, f_cluster, f_center]
+    if with_distance:
+        parts.append(np.sqrt((voxels[:, :, :3] * voxels[:, :, :3]).sum(axis=2, keepdims=True, dtype=F32)).astype(F32))
+    feats = np.concatenate(parts, axis=-1)
     T = voxels.shape[1]
     mask = (num_points.astype(np.int32)[:, None] > np.arange(T, dtype=np.int32)[None, :])
     return feats * mask[..., None].astype(F32)
@@ -54,10 +58,10 @@ def _bn_params(w, prefix):
     return {k: w[f"{prefix}/{k}"] for k in ("gamma", "beta", "moving_mean", "moving_variance")}
 
 
-def pfn_np(voxels, num_points, coors, w, voxel_size, pc_range):
+def pfn_np(voxels, num_points, coors, w, voxel_size, pc_range, with_distance=False):
     """Dense(no bias) -> BN -> ReLU -> max over ALL T rows, incl. zero-padded
     ones (model/pointpillars.py:211-219).  Returns [P,C] fp32."""
-    feats = pfn_decorate_np(voxels, num_points, coors, voxel_size, pc_range)
+    feats = pfn_decorate_np(voxels, num_points, coors, voxel_size, pc_range, with_distance)
     y = feats @ w["pfn/dense/kernel"]
     y = _bn_np(y, _bn_params(w, "pfn/bn"))
     y = np.maximum(y, F32(0))
@@ -127,8 +131,9 @@ def rpn_torch(canvas_nhwc, w, rpn_cfg, num_threads=None):
         out = {
             "box_preds": head(cat, "rpn/conv_box"),
             "cls_preds": head(cat, "rpn/conv_cls"),
-            "dir_cls_preds": head(cat, "rpn/conv_dir_cls"),
         }
+        if "rpn/conv_dir_cls/kernel" in w:     # model/voxelnet.py:690,714: only with use_direction_classifier
+            out["dir_cls_preds"] = head(cat, "rpn/conv_dir_cls")
         return {k: v.permute(0, 2, 3, 1).contiguous().numpy() for k, v in out.items()}
 
 
@@ -171,6 +176,8 @@ def rpn_np(canvas_nhwc, w, rpn_cfg):
     cat = np.concatenate(ups, axis=-1)
     out = {}
     for name, key in (("box_preds", "rpn/conv_box"), ("cls_preds", "rpn/conv_cls"), ("dir_cls_preds", "rpn/conv_dir_cls")):
+        if key + "/kernel" not in w:
+            continue
         out[name] = (cat @ w[key + "/kernel"][0, 0] + w[key + "/bias"]).astype(F32)
     return out
 
@@ -181,7 +188,8 @@ def rpn_np(canvas_nhwc, w, rpn_cfg):
 def voxelnet_forward(voxels, num_points, coors, batch_size, w, model_cfg, num_threads=None):
     """model_cfg: voxel_size, pc_range, grid (nx,ny,nz), rpn{...}.  Returns
     (preds_dict, canvas_nhwc, pillar_features)."""
-    feats = pfn_np(voxels, num_points, coors, w, model_cfg["voxel_size"], model_cfg["pc_range"])
+    feats = pfn_np(voxels, num_points, coors, w, model_cfg["voxel_size"], model_cfg["pc_range"],
+                   bool(model_cfg.get("with_distance", False)))
     nx, ny = int(model_cfg["grid"][0]), int(model_cfg["grid"][1])
     canvas = scatter_np(feats, coors, batch_size, ny, nx)
     preds = rpn_torch(canvas, w, model_cfg["rpn"], num_threads=num_threads)

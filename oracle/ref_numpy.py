@@ -339,9 +339,12 @@ def sigmoid_array(x):
 
 
 def predict(example, preds, cfg):
-    """model/voxelnet.py:1060-1390 for num_class==1, encode_background_as_zeros,
-    use_direction_classifier, no multi-class NMS (the shipped config; the other
-    branches are TF stubs in the reference).
+    """model/voxelnet.py:1060-1390 for encode_background_as_zeros and no multi-class NMS
+    (the shipped config; those other branches are TF stubs in the reference).
+    cfg["num_class"] > 1 follows the stub at :1183-1185 (top_scores = reduce_max,
+    top_labels = argmax over the class scores) restated in numpy -- beyond what the
+    reference can run.  cfg["use_direction_classifier"] False: no dir head, no flip
+    (:1093-1096, :1297).
 
     example: 10-tuple (voxels, num_points, coors, rect, Trv2c, P2, anchors,
     anchors_mask, image_idx, image_shape) of numpy arrays;  preds: dict of
@@ -353,15 +356,25 @@ def predict(example, preds, cfg):
     B = anchors_b.shape[0]
     rect_b, trv_b, mask_b, idx_b = example[3], example[4], example[7], example[8]
     box_b = np.reshape(preds["box_preds"], (B, -1, 7))
-    cls_b = np.reshape(preds["cls_preds"], (B, -1, 1))
-    dir_b = np.reshape(preds["dir_cls_preds"], (B, -1, 2))
+    ncls = int(cfg.get("num_class", 1))
+    use_dir = bool(cfg.get("use_direction_classifier", True))
+    cls_b = np.reshape(preds["cls_preds"], (B, -1, ncls))
+    dir_b = np.reshape(preds["dir_cls_preds"], (B, -1, 2)) if use_dir else [None] * B
     out = []
     for b in range(B):
         sel = np.where(mask_b[b] == 1)[0]
-        box, cls, anc, dirp = box_b[b][sel], cls_b[b][sel], anchors_b[b][sel], dir_b[b][sel]
-        dir_labels = np.argmax(dirp, axis=-1)
-        scores = np.squeeze(sigmoid_array(cls), axis=-1)
-        labels = np.zeros(scores.shape[0], dtype=int)
+        box, cls, anc = box_b[b][sel], cls_b[b][sel], anchors_b[b][sel]
+        if use_dir:
+            dir_labels = np.argmax(dir_b[b][sel], axis=-1)
+        else:
+            dir_labels = np.zeros(box.shape[0], dtype=np.int64)
+        total = sigmoid_array(cls)
+        if ncls == 1:
+            scores = np.squeeze(total, axis=-1)
+            labels = np.zeros(scores.shape[0], dtype=int)
+        else:
+            scores = total.max(axis=-1)
+            labels = np.argmax(total, axis=-1)
         thr = cfg["nms_score_threshold"]
         if thr > 0.0:
             k = scores >= thr
@@ -380,8 +393,9 @@ def predict(example, preds, cfg):
         if selected is not None:
             fbox = box[selected]
             fdir = dir_labels[selected]
-            opp = ((fbox[..., -1] > 0) ^ fdir) > 0  # model/voxelnet.py:1305 precedence
-            fbox[..., -1] += np.where(opp, np.pi, 0.0)
+            if use_dir:
+                opp = ((fbox[..., -1] > 0) ^ fdir) > 0  # model/voxelnet.py:1305 precedence
+                fbox[..., -1] += np.where(opp, np.pi, 0.0)
             cam = box_lidar_to_camera(fbox, rect_b[b], trv_b[b])
             out.append({
                 "bbox": np.tile(np.array([[400., 200., 500., 400.]]), (fbox.shape[0], 1)),

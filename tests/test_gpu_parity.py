@@ -61,8 +61,6 @@ def test_points_to_voxel_reference_signature(pp, hip_lib):
     d = pp.config.Derived(pp.config.pedestrian_d435i_config())
     v, c, n = pp.points_to_voxel(g["a2k_points"], d.voxel_size, d.pc_range, 50, True, 12000)
     assert np.array_equal(c, g["a2k_coors"]) and np.array_equal(n, g["a2k_num"]) and np.array_equal(v, g["a2k_voxels"])
-    with pytest.raises(NotImplementedError):
-        pp.points_to_voxel(g["a2k_points"], d.voxel_size, d.pc_range, 50, False, 12000)
 
 
 def test_voxelise_edge_cases(pp, engines):

@@ -43,10 +43,22 @@ def test_config_derivation(pp):
     assert d.pfn_in == 8 and d.concat_channels == 384
     k = c.Derived(c.kitti_shaped_config())
     assert (k.nx, k.ny, k.nz, k.head_h, k.head_w, k.num_anchors) == (432, 496, 1, 248, 216, 107136)
+    two = c.Derived(c.kitti_shaped_config(num_class=2))        # 2 * (7 + 2 + 2) = 22 head columns
+    assert two.num_class == 2 and two.num_anchor_per_loc == 2
     bad = c.pedestrian_d435i_config()
-    bad["model"]["second"]["num_class"] = 2
+    bad["model"]["second"]["num_class"] = 8                    # 2 * (7 + 8 + 2) = 34 > 32 head columns
     with pytest.raises(NotImplementedError):
         c.Derived(bad)
+    bad = c.pedestrian_d435i_config()
+    bad["model"]["second"]["use_multi_class_nms"] = True       # TF stub in the reference
+    with pytest.raises(NotImplementedError):
+        c.Derived(bad)
+    nd = c.pedestrian_d435i_config()
+    nd["model"]["second"]["use_direction_classifier"] = False
+    nd["model"]["second"]["voxel_feature_extractor"]["with_distance"] = True
+    dd = c.Derived(nd)
+    assert dd.pfn_in == 9 and not dd.use_direction_classifier
+    assert "rpn/conv_dir_cls/kernel" not in pp.weights.init_weights(dd, seed=1)
     bad = c.pedestrian_d435i_config()
     bad["model"]["second"]["rpn"]["upsample_strides"] = [1, 2, 2]
     with pytest.raises(ValueError):
@@ -94,12 +106,12 @@ def test_cabi_exports_every_declared_symbol(pp, hip_lib):
     assert declared == set(pp._lib.EXPORTS), declared ^ set(pp._lib.EXPORTS)
     for name in declared:
         assert hasattr(hip_lib, name), name
-    assert hip_lib.pp_abi_version() == 1
+    assert hip_lib.pp_abi_version() == 2
 
 
 def test_struct_layouts_match_header(pp):
     assert ctypes.sizeof(pp._lib.PPDetection) == 104
-    assert ctypes.sizeof(pp._lib.PPConfig) == 72 + 4 * 4 + 15 * 4 + 2 * 4 + 2 * 4 + 3 * 4 + 2 * 4
+    assert ctypes.sizeof(pp._lib.PPConfig) == 72 + 4 * 4 + 15 * 4 + 2 * 4 + 2 * 4 + 3 * 4 + 2 * 4 + 2 * 4
 
 
 def test_no_cpu_fallback(pp, hip_lib):

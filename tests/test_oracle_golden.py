@@ -133,3 +133,15 @@ def test_nms_iou_formula_matches_reference_device_function():
         for ci, j in enumerate(g["cols"]):
             assert abs(rn.nms_iou(b[i], b[j]) - g["iou"][ri, ci]) < 1e-6
     assert (g["iou"] > 0.5).sum() > 20 and (g["iou"] == 0.0).sum() > 20
+
+
+def test_oracle_voxelise_forward_index_matches_reference():
+    """reverse_index=False (load_data.py:643-692): the restatement against the reference's own output."""
+    g, gf = load_golden("ref_voxel.npz"), load_golden("ref_voxel_fwd.npz")
+    import pp_amd
+    d = pp_amd.config.Derived(pp_amd.config.pedestrian_d435i_config())
+    for case in ("a2k", "brk"):
+        T, MV = (int(v) for v in gf[case + "_params"])
+        v, c, n = rn.points_to_voxel(g[case + "_points"], d.voxel_size, d.pc_range, T, False, MV)
+        assert np.array_equal(c, gf[case + "_coors"]) and np.array_equal(n, gf[case + "_num"])
+        assert np.array_equal(v, gf[case + "_voxels"])
