@@ -11,6 +11,7 @@ from .voxel_generator import points_to_voxel  # noqa: F401
 from .engine import Engine  # noqa: F401
 from .voxelnet import VoxelNet  # noqa: F401
 from .dataprep import prep_example, merge_batch  # noqa: F401
+from .trainer import Trainer  # noqa: F401
 
-__all__ = ["config", "anchors", "weights", "synth", "frame_shard", "anno", "kitti_eval", "ingest", "target_assigner", "optim", "points_to_voxel", "Engine", "VoxelNet",
+__all__ = ["config", "anchors", "weights", "synth", "frame_shard", "anno", "kitti_eval", "ingest", "target_assigner", "optim", "points_to_voxel", "Engine", "VoxelNet", "Trainer",
            "prep_example", "merge_batch"]

@@ -18,7 +18,7 @@ _INCLUDE = os.path.join(os.path.dirname(_PKG), "include", "pp_hip.h")
 SO_PATH = os.path.join(_PKG, os.environ.get("PP_HIP_LIB", "libpp_hip.so"))
 _VARIANT = os.path.splitext(os.path.basename(SO_PATH))[0]
 SOURCES = ["pp_api.hip", "voxelize.hip", "pfn.hip", "anchor_mask.hip", "backbone.hip", "postprocess.hip",
-           "rotate_iou.hip", "loss.hip", "optim.hip"]
+           "rotate_iou.hip", "loss.hip", "optim.hip", "train.hip"]
 # -fno-slp-vectorize: keeps f32 FMAs as v_fma_f32; the SLP vectoriser's v_pk_fma_f32 is slow on a SIMD
 # that is also issuing MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
@@ -32,6 +32,7 @@ EXPORTS = [
     "pp_get_detections", "pp_detect", "pp_fetch_intermediates", "pp_set_profiling", "pp_get_kernel_times",
     "pp_timer_start", "pp_timer_stop", "pp_device_info", "pp_bench_layer", "pp_layer_count", "pp_layer_tag",
     "pp_rotate_iou_eval", "pp_d3_box_overlap", "pp_head_loss", "pp_adamw_step_device",
+    "pp_train_layout", "pp_train_layout_entry", "pp_train_step",
 ]
 
 
@@ -103,7 +104,7 @@ _EXTRA = os.environ.get("PP_HIPCC_EXTRA", "").split()
 
 
 def _deps():
-    return [os.path.join(_CSRC, "pp_common.h"), _INCLUDE]
+    return [os.path.join(_CSRC, "pp_common.h"), os.path.join(_CSRC, "train.h"), _INCLUDE]
 
 
 def needs_build():
@@ -209,6 +210,10 @@ def lib():
     L.pp_rotate_iou_eval.argtypes = [ctypes.c_int, f32p, i64, f32p, i64, i32, f32p]
     L.pp_d3_box_overlap.argtypes = [ctypes.c_int, vp, i64, vp, i64, i32, vp]
     L.pp_head_loss.argtypes = [vp, vp, f32p, i32, ctypes.POINTER(PPLossConfig), f32p, f32p]
+    L.pp_train_layout.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.pp_train_layout_entry.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64), ctypes.POINTER(i64),
+                                        ctypes.POINTER(i32)]
+    L.pp_train_step.argtypes = [vp, vp, vp, vp, vp, f32p, i32, ctypes.POINTER(PPLossConfig), f32p]
     L.pp_adamw_step_device.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, i64, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_float]
     for name in EXPORTS:

@@ -42,6 +42,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));   // (name kept: "one 8-element piece operand")
 #define PC_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
 #endif
+// third (lowest) piece of a pre-split operand in LDS: exists only in the three-piece mode
+#if PP_SPLIT_MODE == 0
+#define PC_LO(PTR) (*reinterpret_cast<const bf16x8*>(PTR))
+#else
+#define PC_LO(PTR) (bf16x8{})
+#endif
 // ACC += X * Y with X the first MFMA operand; smallest terms first
 #if PP_SPLIT_MODE == 0
 #define PC_PRODUCTS(ACC, XH, XM, XL, YH, YM, YL) \
@@ -941,7 +947,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                             \
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);                         \
             const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);                \
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);            \
+            [[maybe_unused]] const bf16x8 bl = PC_LO(cB + 2 * NT * 8 + n * 32 * 8);            \
             PC_PRODUCTS(acc[n], ah, am, al, bh, bm, bl)                                                  \
         }                                                                                                \
     }                                                                                                    \
@@ -1234,7 +1240,7 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
             for (int n = 0; n < NTILES; ++n) {
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);
                 const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);
+                [[maybe_unused]] const bf16x8 bl = PC_LO(cB + 2 * NT * 8 + n * 32 * 8);
                 PC_PRODUCTS(acc[n], ah, am, al, bh, bm, bl)
             }
         }
@@ -1341,7 +1347,7 @@ __device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (
                 const float* hW = sHW + ((n * 2 + g) * PP_NPIECE * 32 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
                 const bf16x8 wh = *reinterpret_cast<const bf16x8*>(hW);
                 const bf16x8 wm = *reinterpret_cast<const bf16x8*>(hW + 32 * 8);
-                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(hW + 2 * 32 * 8);
+                [[maybe_unused]] const bf16x8 wl = PC_LO(hW + 2 * 32 * 8);
                 PC_PRODUCTS(hacc, wh, wm, wl, xh, xm, xl)
             }
         }
@@ -1510,7 +1516,7 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
             _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                         \
                 const bf16x8 bh_ = *reinterpret_cast<const bf16x8*>(cB_ + n * 32 * 8);                   \
                 const bf16x8 bm_ = *reinterpret_cast<const bf16x8*>(cB_ + NT * 8 + n * 32 * 8);          \
-                const bf16x8 bl_ = *reinterpret_cast<const bf16x8*>(cB_ + 2 * NT * 8 + n * 32 * 8);      \
+                [[maybe_unused]] const bf16x8 bl_ = PC_LO(cB_ + 2 * NT * 8 + n * 32 * 8);      \
                 PC_PRODUCTS(acc[n], bh_, bm_, bl_, ah_, am_, al_)                                        \
             }                                                                                            \
         }                                                                                                \
@@ -1636,7 +1642,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
             for (int n = 0; n < NTILES; ++n) {
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);
                 const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + NT * 8 + n * 32 * 8);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(cB + 2 * NT * 8 + n * 32 * 8);
+                [[maybe_unused]] const bf16x8 bl = PC_LO(cB + 2 * NT * 8 + n * 32 * 8);
                 PC_PRODUCTS(acc[n], bh, bm, bl, ah, am, al)
             }
         }
@@ -1702,7 +1708,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
                 const float* hW = sHW + ((wave * 2 + g) * PP_NPIECE * 32 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
                 const bf16x8 wh = *reinterpret_cast<const bf16x8*>(hW);
                 const bf16x8 wm = *reinterpret_cast<const bf16x8*>(hW + 32 * 8);
-                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(hW + 2 * 32 * 8);
+                [[maybe_unused]] const bf16x8 wl = PC_LO(hW + 2 * 32 * 8);
                 PC_PRODUCTS(hpart, wh, wm, wl, xh, xm, xl)
             }
         }

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "pp_common.h"
+#include "train.h"
 
 extern int g_num_cus;   // backbone.hip: CU count for persistent launches
 
@@ -108,6 +109,16 @@ struct pp_engine {
     hipEvent_t off_ev[OFF_RING] = {nullptr, nullptr, nullptr, nullptr};
     int off_slot = 0;
     hipEvent_t ev_in = nullptr;   // orders the engine's stream behind a producer stream (pp_upload_points_device)
+
+    // training step (train.hip): shapes, flat layout and device buffers, set up by the first pp_train_* call
+    struct TrainState {
+        TrainShape shape;
+        std::vector<TrainEntry> layout;
+        int64_t n_params = 0, n_state = 0;
+        TrainCtx cx;
+        bool buffers = false;
+    };
+    TrainState* train = nullptr;
 
     int prof = 0;
     // pp_detect_async as one hipGraph launch (captured on first use per (batch, max points per frame))
@@ -740,6 +751,7 @@ int pp_destroy(pp_handle e) {
     graph_invalidate(e);
     for (void* p : e->allocs) (void)hipFree(p);
     for (void* p : e->wallocs) (void)hipFree(p);
+    delete e->train;
     if (e->h_off_ring) (void)hipHostFree(e->h_off_ring);
     for (hipEvent_t ev : e->off_ev) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -1435,6 +1447,100 @@ int pp_d3_box_overlap(int device, const double* boxes, int64_t n, const double* 
     return PP_OK;
 }
 
+// ---- training step ----
+namespace {
+
+int ensure_loss_buffers(pp_engine* e) {
+    if (e->d_head_grad) return PP_OK;
+    const size_t npx = (size_t)e->head_h * e->head_w;
+    int st;
+    if ((st = dalloc(e, &e->d_loss_labels, (size_t)e->B * e->A))) return st;
+    if ((st = dalloc(e, &e->d_loss_regt, (size_t)e->B * e->A * 7))) return st;
+    if ((st = dalloc(e, &e->d_loss_npos, (size_t)e->B))) return st;
+    if ((st = dalloc(e, &e->d_loss_partials, (size_t)e->B * loss_blocks((int)npx) * 5))) return st;
+    if ((st = dalloc(e, &e->d_loss_out, (size_t)8))) return st;
+    if ((st = dalloc(e, &e->d_head_grad, (size_t)e->B * npx * PP_HEAD_COLS))) return st;
+    return PP_OK;
+}
+
+void fill_loss_params(pp_engine* e, const pp_loss_config* lc, int batch, LossParams& p) {
+    memset(&p, 0, sizeof(p));
+    p.batch = batch; p.A = e->A; p.npx = e->head_h * e->head_w; p.napl = e->napl;
+    p.head = e->d_head; p.labels = e->d_loss_labels; p.reg_targets = e->d_loss_regt; p.anchors = e->d_anchors;
+    p.npos = e->d_loss_npos; p.partials = e->d_loss_partials; p.losses = e->d_loss_out;
+    p.alpha = lc->alpha; p.gamma = lc->gamma; p.sigma = lc->sigma;
+    for (int i = 0; i < 7; ++i) p.code_weight[i] = lc->code_weight[i];
+    p.pos_cls_weight = lc->pos_class_weight; p.neg_cls_weight = lc->neg_class_weight;
+    p.cls_weight = lc->classification_weight; p.loc_weight = lc->localization_weight; p.dir_weight = lc->direction_loss_weight;
+    p.norm_by_num_positives = lc->norm_by_num_positives; p.encode_rad_error_by_sin = lc->encode_rad_error_by_sin;
+    p.use_direction = lc->use_direction_classifier;
+}
+
+int train_state(pp_engine* e) {
+    if (e->train) return PP_OK;
+    auto* t = new pp_engine::TrainState();
+    TrainShape& s = t->shape;
+    s.nx = e->nx; s.ny = e->ny; s.nz = e->nz; s.C = e->C; s.F = e->F; s.FA = e->FA; s.T = e->T;
+    s.max_voxels = e->cfg.max_voxels; s.with_dist = e->with_dist ? 1 : 0;
+    s.vx = (float)e->cfg.voxel_size[0]; s.vy = (float)e->cfg.voxel_size[1];
+    s.x_off = (float)(e->cfg.voxel_size[0] / 2 + e->cfg.pc_range[0]);
+    s.y_off = (float)(e->cfg.voxel_size[1] / 2 + e->cfg.pc_range[1]);
+    s.head_h = e->head_h; s.head_w = e->head_w; s.napl = e->napl; s.ncls = e->ncls; s.use_dir = e->use_dir ? 1 : 0;
+    s.CC = e->CC;
+    s.layers = e->layers;
+    t->layout = train_layout(s, &t->n_params, &t->n_state);
+    e->train = t;
+    return PP_OK;
+}
+
+int train_buffers(pp_engine* e) {
+    pp_engine::TrainState* t = e->train;
+    if (t->buffers) return PP_OK;
+    const TrainShape& s = t->shape;
+    TrainCtx& cx = t->cx;
+    const size_t B = (size_t)e->B, HW = (size_t)s.head_h * s.head_w;
+    int st = PP_OK;
+    auto A1 = [&](int r) { if (st == PP_OK) st = r; };
+    A1(dalloc(e, &cx.pfn_y, B * e->NMAX * s.C));
+    A1(dalloc(e, &cx.pfn_feat, B * s.max_voxels * s.C));
+    A1(dalloc(e, &cx.pfn_arg, B * s.max_voxels * s.C));
+    A1(dalloc(e, &cx.pfn_stats, (size_t)2 * s.C));
+    A1(dalloc(e, &cx.pfn_sums, (size_t)2 * s.C));
+    A1(dalloc(e, &cx.canvas, B * s.ny * s.nx * s.C));
+    A1(dalloc(e, &cx.dcanvas, B * s.ny * s.nx * s.C));
+    size_t max_z = 1, max_d = 1;
+    cx.lbuf.assign(s.layers.size(), TrainLayerBuf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+    for (size_t i = 0; i < s.layers.size(); ++i) {
+        const LayerDesc& l = s.layers[i];
+        TrainLayerBuf& tb = cx.lbuf[i];
+        if (l.kind == LAYER_SEP) {
+            const size_t rows = B * l.out_h * l.out_w;
+            A1(dalloc(e, &tb.D, rows * l.cin)); A1(dalloc(e, &tb.Z, rows * l.cout));
+            A1(dalloc(e, &tb.A, rows * l.cout)); A1(dalloc(e, &tb.dA, rows * l.cout));
+            max_z = std::max(max_z, rows * l.cout); max_d = std::max(max_d, rows * l.cin);
+        } else if (l.kind == LAYER_DECONV) {
+            const size_t n = B * l.in_h * l.in_w * l.k * l.k * l.cout;
+            A1(dalloc(e, &tb.Z, n));
+            max_z = std::max(max_z, n);
+        } else {
+            continue;
+        }
+        A1(dalloc(e, &tb.stats, (size_t)2 * l.cout)); A1(dalloc(e, &tb.sums, (size_t)2 * l.cout));
+    }
+    A1(dalloc(e, &cx.cat, B * HW * s.CC)); A1(dalloc(e, &cx.dcat, B * HW * s.CC));
+    A1(dalloc(e, &cx.head_w, (size_t)s.CC * PP_HEAD_COLS)); A1(dalloc(e, &cx.head_b, (size_t)PP_HEAD_COLS));
+    A1(dalloc(e, &cx.dhead_w, (size_t)s.CC * PP_HEAD_COLS)); A1(dalloc(e, &cx.dhead_b, (size_t)2 * PP_HEAD_COLS));
+    A1(dalloc(e, &cx.dZ, max_z)); A1(dalloc(e, &cx.dD, max_d));
+    A1(dalloc(e, &cx.part, train_part_floats(s)));
+    cx.gemm_part_floats = 16l << 20;   // 64 MB of split-K partial tiles
+    A1(dalloc(e, &cx.gemm_part, (size_t)cx.gemm_part_floats));
+    if (st == PP_OK) st = ensure_loss_buffers(e);
+    if (st == PP_OK) t->buffers = true;
+    return st;
+}
+
+}  // namespace
+
 int pp_head_loss(pp_handle e, const int32_t* labels, const float* reg_targets, int32_t batch,
                  const pp_loss_config* lc, float* losses, float* head_grad) {
     if (!e) return PP_ERR_ARG;
@@ -1446,28 +1552,12 @@ int pp_head_loss(pp_handle e, const int32_t* labels, const float* reg_targets, i
     if (e->cfg.num_class != 1 || !e->use_dir) return fail(e, PP_ERR_UNSUPPORTED, "pp_head_loss: one class with the direction head only (the shipped training config)");
     (void)hipSetDevice(e->device);
     const size_t npx = (size_t)e->head_h * e->head_w;
-    if (!e->d_head_grad) {   // training-side buffers: allocated on first use
-        if ((st = dalloc(e, &e->d_loss_labels, (size_t)e->B * e->A))) return st;
-        if ((st = dalloc(e, &e->d_loss_regt, (size_t)e->B * e->A * 7))) return st;
-        if ((st = dalloc(e, &e->d_loss_npos, (size_t)e->B))) return st;
-        if ((st = dalloc(e, &e->d_loss_partials, (size_t)e->B * loss_blocks((int)npx) * 5))) return st;
-        if ((st = dalloc(e, &e->d_loss_out, (size_t)8))) return st;
-        if ((st = dalloc(e, &e->d_head_grad, (size_t)e->B * npx * PP_HEAD_COLS))) return st;
-    }
+    if ((st = ensure_loss_buffers(e))) return st;
     HIPCHK(e, hipMemcpyAsync(e->d_loss_labels, labels, (size_t)batch * e->A * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->d_loss_regt, reg_targets, (size_t)batch * e->A * 7 * sizeof(float), hipMemcpyHostToDevice, e->stream));
     LossParams p;
-    memset(&p, 0, sizeof(p));
-    p.batch = batch; p.A = e->A; p.npx = (int)npx; p.napl = e->napl;
-    p.head = e->d_head; p.labels = e->d_loss_labels; p.reg_targets = e->d_loss_regt; p.anchors = e->d_anchors;
-    p.npos = e->d_loss_npos; p.partials = e->d_loss_partials; p.losses = e->d_loss_out;
+    fill_loss_params(e, lc, batch, p);
     p.head_grad = head_grad ? e->d_head_grad : nullptr;
-    p.alpha = lc->alpha; p.gamma = lc->gamma; p.sigma = lc->sigma;
-    for (int i = 0; i < 7; ++i) p.code_weight[i] = lc->code_weight[i];
-    p.pos_cls_weight = lc->pos_class_weight; p.neg_cls_weight = lc->neg_class_weight;
-    p.cls_weight = lc->classification_weight; p.loc_weight = lc->localization_weight; p.dir_weight = lc->direction_loss_weight;
-    p.norm_by_num_positives = lc->norm_by_num_positives; p.encode_rad_error_by_sin = lc->encode_rad_error_by_sin;
-    p.use_direction = lc->use_direction_classifier;
     {
         ProfScope ps(e, "k_loss_pixels:loss+grad", true);
         if ((st = launch_head_loss(p, e->stream))) return fail(e, st, "pp_head_loss: %d anchors per pixel not supported", e->napl);
@@ -1477,6 +1567,77 @@ int pp_head_loss(pp_handle e, const int32_t* labels, const float* reg_targets, i
     if (head_grad)
         HIPCHK(e, hipMemcpyAsync(head_grad, e->d_head_grad, (size_t)batch * npx * PP_HEAD_COLS * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    return PP_OK;
+}
+
+int pp_train_layout(pp_handle e, int32_t* n_entries, int64_t* n_param_floats, int64_t* n_state_floats) {
+    if (!e) return PP_ERR_ARG;
+    int st = train_state(e); if (st) return st;
+    if (n_entries) *n_entries = (int32_t)e->train->layout.size();
+    if (n_param_floats) *n_param_floats = e->train->n_params;
+    if (n_state_floats) *n_state_floats = e->train->n_state;
+    return PP_OK;
+}
+
+int pp_train_layout_entry(pp_handle e, int32_t i, const char** name, int64_t* offset, int64_t* size, int32_t* is_state) {
+    if (!e) return PP_ERR_ARG;
+    int st = train_state(e); if (st) return st;
+    if (i < 0 || i >= (int)e->train->layout.size()) return fail(e, PP_ERR_ARG, "pp_train_layout_entry: index %d out of range", i);
+    const TrainEntry& t = e->train->layout[i];
+    if (name) *name = t.name.c_str();
+    if (offset) *offset = t.offset;
+    if (size) *size = t.size;
+    if (is_state) *is_state = t.is_state;
+    return PP_OK;
+}
+
+int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float* state_dev, const int32_t* labels,
+                  const float* reg_targets, int32_t batch, const pp_loss_config* lc, float* losses) {
+    if (!e) return PP_ERR_ARG;
+    if (!params_dev || !grads_dev || !state_dev || !labels || !reg_targets || !lc || !losses)
+        return fail(e, PP_ERR_ARG, "pp_train_step: null argument");
+    if (!e->anchors_ready) return fail(e, PP_ERR_STATE, "pp_train_step: anchors not set");
+    if (e->cur_batch < 1 || e->cur_batch != batch)
+        return fail(e, PP_ERR_STATE, "pp_train_step: %d frames are resident, batch is %d (upload the frames first)", e->cur_batch, batch);
+    if (e->cfg.num_class != 1 || !e->use_dir)
+        return fail(e, PP_ERR_UNSUPPORTED, "pp_train_step: one class with the direction head only (the shipped training config)");
+    if (!(lc->sigma > 0.f)) return fail(e, PP_ERR_ARG, "pp_train_step: sigma must be positive");
+    (void)hipSetDevice(e->device);
+    int st = train_state(e); if (st) return st;
+    if ((st = train_buffers(e))) return st;
+    if (e->up_pending) {
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_up, 0));
+        e->up_pending = false;
+    }
+    prof_reset(e);
+    if ((st = run_voxelize(e, batch, e->cur_max_n))) return st;
+    std::vector<int> np((size_t)batch);
+    HIPCHK(e, hipMemcpyAsync(np.data(), e->d_npillars, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_loss_labels, labels, (size_t)batch * e->A * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_loss_regt, reg_targets, (size_t)batch * e->A * 7 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    long total_p = 0;
+    for (int v : np) total_p += v;
+    if (total_p < 1) return fail(e, PP_ERR_ARG, "pp_train_step: the batch has no pillar");
+    pp_engine::TrainState* t = e->train;
+    TrainCtx& cx = t->cx;
+    cx.stream = e->stream;
+    cx.pts_sorted = e->d_points_sorted; cx.offsets = e->d_offsets; cx.pillar_start = e->d_pstart; cx.pillar_cell = e->d_pcell;
+    cx.npillars = e->d_npillars; cx.cellmap = e->d_cellmap;
+    cx.head = e->d_head; cx.dhead = e->d_head_grad;
+    LossParams lp;
+    fill_loss_params(e, lc, batch, lp);
+    {
+        ProfScope ps(e, nullptr);
+        st = train_step(cx, t->shape, t->layout, params_dev, grads_dev, state_dev, batch, (int)total_p, lp);
+    }
+    if (st) return fail(e, st, "pp_train_step: configuration not supported by the training kernels");
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipMemcpyAsync(losses, e->d_loss_out, 8 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipEventRecord(e->ev_read[e->in_buf], e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->results_batch = 0;          // the head map now holds training-mode outputs, not detections
+    e->cls_plane_live = false;
     return PP_OK;
 }
 

@@ -371,6 +371,36 @@ class Engine:
             out["dir_cls_preds_grad"] = grad[:, :, nb + na:nb + 3 * na].reshape(batch, hh, hw, 2 * na)
         return out
 
+    # ---- training step (f3) ----
+    def train_layout(self):
+        """[(name, offset, size, is_state)] of the flat parameter / BatchNorm-state buffers (pp_train_layout)."""
+        n, npar, nst = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._lib.pp_train_layout(self._h, ctypes.byref(n), ctypes.byref(npar), ctypes.byref(nst)), "pp_train_layout")
+        out = []
+        for i in range(n.value):
+            name, off, size, st = ctypes.c_char_p(), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int32(0)
+            self._check(self._lib.pp_train_layout_entry(self._h, i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(size),
+                                                        ctypes.byref(st)), "pp_train_layout_entry")
+            out.append((name.value.decode(), off.value, size.value, bool(st.value)))
+        return out, npar.value, nst.value
+
+    def train_step(self, params_ptr, grads_ptr, state_ptr, labels, reg_targets):
+        """Forward (training mode) + loss + backward on the resident frames (pp_train_step).  The three pointers
+        are integer device addresses of the flat float32 buffers; returns the reference's loss scalars."""
+        labels = _i32(np.asarray(labels))
+        batch = labels.shape[0]
+        reg_targets = _f32(np.asarray(reg_targets).reshape(batch, self.d.num_anchors, 7))
+        if labels.shape != (batch, self.d.num_anchors):
+            raise ValueError(f"labels must be [B, {self.d.num_anchors}]")
+        losses = np.zeros(8, np.float32)
+        lc = self.loss_config()
+        self._check(self._lib.pp_train_step(self._h, ctypes.c_void_p(int(params_ptr)), ctypes.c_void_p(int(grads_ptr)),
+                                            ctypes.c_void_p(int(state_ptr)), _ptr(labels), _ptr(reg_targets), batch,
+                                            ctypes.byref(lc), _ptr(losses)), "pp_train_step")
+        return {"loss": float(losses[0]), "loc_loss_reduced": float(losses[1]), "cls_loss_reduced": float(losses[2]),
+                "dir_loss_reduced": float(losses[3]), "cls_pos_loss": float(losses[4]), "cls_neg_loss": float(losses[5]),
+                "num_positives": int(losses[6])}
+
     def timer_start(self):
         self._check(self._lib.pp_timer_start(self._h), "pp_timer_start")
 

@@ -1,0 +1,92 @@
+"""Training loop body of train.py:228-304 on the HIP engine.
+
+    trainer = Trainer(config, weights, max_batch=2)            # one per GPU / rank
+    out = trainer.step(frames, labels, reg_targets, dist)      # forward + loss + backward, all-reduce, AdamW
+    trainer.weights()                                          # Keras-layout dict (Engine.load_weights, save_npz)
+
+What runs where: the frames are uploaded and voxelised by the engine, `pp_train_step` (csrc/train.hip) runs the
+training-mode forward pass, the loss and the backward pass and leaves the gradients of all trainable tensors in one
+flat float32 buffer; that buffer is averaged over the ranks with ONE all-reduce (`torch.distributed`, backend
+"nccl" = RCCL over xGMI; BatchNorm statistics stay per replica, as in the single-GPU reference) and consumed by the
+AdamW kernel (csrc/optim.hip).  torch owns the flat device buffers and the communicator; no torch operator touches
+the numbers.  Labels / regression targets come from `target_assigner` (the reference's training dataloader).
+"""
+import numpy as np
+
+from . import optim
+from .engine import Engine
+
+
+class Trainer:
+    def __init__(self, config, weights, max_batch=None, max_points_per_frame=32768, device=0, learning_rate=None,
+                 weight_decay=None):
+        import torch
+        self.torch = torch
+        self.engine = Engine(config, max_batch=max_batch, max_points_per_frame=max_points_per_frame, device=device)
+        d = self.engine.d
+        self.layout, n_params, n_state = self.engine.train_layout()
+        self.device = torch.device("cuda", device)
+        self.params = torch.zeros(n_params, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.state = torch.zeros(n_state, dtype=torch.float32, device=self.device)
+        self.set_weights(weights)
+        tc = config.get("train_config", {}) if isinstance(config, dict) else {}
+        if learning_rate is None:
+            try:
+                learning_rate = optim.ExponentialDecay.from_config(tc, max_batch or d.batch_size)
+            except (KeyError, TypeError):
+                learning_rate = 2e-4
+        if weight_decay is None:
+            try:
+                weight_decay = float(tc["optimizer"]["adam_optimizer"]["weight_decay"])
+            except (KeyError, TypeError):
+                weight_decay = 1e-4
+        self.optimizer = optim.AdamW(self.params, learning_rate, weight_decay)
+
+    # ---- Keras-layout dict <-> flat buffers ----
+    def set_weights(self, w):
+        p = np.zeros(self.params.numel(), np.float32)
+        s = np.zeros(self.state.numel(), np.float32)
+        for name, off, size, is_state in self.layout:
+            a = np.ascontiguousarray(w[name], dtype=np.float32).reshape(-1)
+            if a.size != size:
+                raise ValueError(f"weight {name!r}: {a.size} values, the layout expects {size}")
+            (s if is_state else p)[off:off + size] = a
+        self.params.copy_(self.torch.from_numpy(p))
+        self.state.copy_(self.torch.from_numpy(s))
+
+    def _unflatten(self, flat_params, flat_state, like):
+        out = {}
+        for name, off, size, is_state in self.layout:
+            src = flat_state if is_state else flat_params
+            out[name] = src[off:off + size].reshape(like[name].shape).copy()
+        return out
+
+    def weights(self):
+        from . import weights as _w
+        shapes = _w.expected_shapes(self.engine.d)
+        like = {k: np.empty(v, np.float32) for k, v in shapes.items()}
+        return self._unflatten(self.params.cpu().numpy(), self.state.cpu().numpy(), like)
+
+    def gradients(self):
+        """The last step's gradients as a Keras-layout dict (trainable tensors only)."""
+        from . import weights as _w
+        shapes = _w.expected_shapes(self.engine.d)
+        g = self.grads.cpu().numpy()
+        return {name: g[off:off + size].reshape(shapes[name]).copy() for name, off, size, st in self.layout if not st}
+
+    # ---- one optimizer step ----
+    def forward_backward(self, frames, labels, reg_targets):
+        self.engine.upload(frames)
+        return self.engine.train_step(self.params.data_ptr(), self.grads.data_ptr(), self.state.data_ptr(), labels,
+                                      reg_targets)
+
+    def step(self, frames, labels, reg_targets, dist=None):
+        out = self.forward_backward(frames, labels, reg_targets)
+        optim.allreduce_gradients(self.grads, dist)        # one collective per step over the flat buffer
+        self.optimizer.apply_gradients(self.grads)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return out
+
+    def close(self):
+        self.engine.close()

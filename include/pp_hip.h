@@ -275,6 +275,29 @@ int pp_head_loss(pp_handle h, const int32_t* labels, const float* reg_targets, i
 int pp_adamw_step_device(int device, void* stream, float* params, const float* grads, float* m, float* v,
                          int64_t n, float lr_t, float beta1, float beta2, float epsilon, float weight_decay);
 
+/* ---- training step ---------------------------- */
+
+/* The trainable tensors live in ONE flat float32 device buffer owned by the caller (a second one of the same
+ * order receives the gradients, a third, smaller one holds the BatchNorm moving statistics): what the AdamW kernel
+ * above and the data-parallel all-reduce work on.  These two calls describe the order: entry i is the Keras tensor
+ * `name` (layouts of <package>/weights.py: depthwise [3,3,Cin,1], pointwise [1,1,Cin,Cout], Conv2DTranspose
+ * [k,k,Cout,Cin], Dense [Fa,C], heads [1,1,Cin,Cout] + bias), `size` floats at `offset` of the parameter buffer
+ * (is_state 0) or of the state buffer (is_state 1: moving_mean / moving_variance).  `name` stays valid for the
+ * life of the handle. */
+int pp_train_layout(pp_handle h, int32_t* n_entries, int64_t* n_param_floats, int64_t* n_state_floats);
+int pp_train_layout_entry(pp_handle h, int32_t i, const char** name, int64_t* offset, int64_t* size, int32_t* is_state);
+
+/* Replaces one trainStep of train.py:265-304 up to (not including) optimizer.apply_gradients: VoxelNet.call in
+ * training mode (model/voxelnet.py:850-1049: PillarFeatureNet, scatter, RPN with batch-statistics BatchNorm, the
+ * losses) on the `batch` frames resident in the handle (pp_upload_points*; they are voxelised here), and the
+ * gradient of `loss` with respect to every trainable tensor.  params_dev / grads_dev / state_dev: DEVICE pointers to
+ * the flat buffers described by pp_train_layout (grads overwritten; the moving statistics in state_dev updated in
+ * place as Keras does).  labels [batch][A] int32, reg_targets [batch][A][7] float32: HOST pointers, the dataloader's
+ * targets (load_data.py:3096-3100).  losses[8] as pp_head_loss.  Runs on the handle's stream and returns when the
+ * step has finished (the caller then all-reduces grads_dev and calls pp_adamw_step_device). */
+int pp_train_step(pp_handle h, const float* params_dev, float* grads_dev, float* state_dev, const int32_t* labels,
+                  const float* reg_targets, int32_t batch, const pp_loss_config* cfg, float* losses);
+
 /* Device properties for reports: name (<=255 chars), CU count, bytes of HBM. */
 int pp_device_info(pp_handle h, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes);
 

@@ -13,14 +13,11 @@ import numpy as np
 import torch
 
 
-def training_loss(second_cfg, box_preds, cls_preds, dir_cls_preds, labels, reg_targets, anchors, dtype=torch.float32):
-    """box_preds [B,H,W,na*7], cls_preds [B,H,W,na], dir_cls_preds [B,H,W,na*2] (numpy), labels [B,A] int,
-    reg_targets [B,A,7], anchors [A,7].  Returns (dict of python floats, dict of numpy gradients)."""
+def loss_tensors(second_cfg, box, cls, dr, labels, reg_targets, anchors, dtype=torch.float32):
+    """The loss graph on torch tensors (box / cls / dr may carry an autograd history: the whole-network gradient
+    check of oracle/train_ref.py).  Returns a dict of 0-d tensors."""
     s = second_cfg
     B = labels.shape[0]
-    box = torch.tensor(np.asarray(box_preds), dtype=dtype, requires_grad=True)
-    cls = torch.tensor(np.asarray(cls_preds), dtype=dtype, requires_grad=True)
-    dr = torch.tensor(np.asarray(dir_cls_preds), dtype=dtype, requires_grad=True)
     labels_t = torch.tensor(np.asarray(labels), dtype=torch.int64)
     reg_t = torch.tensor(np.asarray(reg_targets), dtype=dtype).reshape(B, -1, 7)
     anc = torch.tensor(np.asarray(anchors), dtype=dtype).reshape(1, -1, 7)
@@ -77,11 +74,20 @@ def training_loss(second_cfg, box_preds, cls_preds, dir_cls_preds, labels, reg_t
         ce_dir = torch.nn.functional.cross_entropy(logits.reshape(-1, 2), dir_t.reshape(-1), reduction="none")
         dir_red = (ce_dir.reshape(B, -1) * w).sum() / B * s["direction_loss_weight"]
         loss = loss + dir_red
-    loss.backward()
-    vals = {"loss": float(loss.detach()), "loc_loss_reduced": float(loc_red.detach()),
-            "cls_loss_reduced": float(cls_red.detach()), "dir_loss_reduced": float(dir_red.detach()),
-            "cls_pos_loss": float(cls_pos.detach()), "cls_neg_loss": float(cls_neg.detach()),
-            "num_positives": int((labels_t > 0).sum())}
+    return {"loss": loss, "loc_loss_reduced": loc_red, "cls_loss_reduced": cls_red, "dir_loss_reduced": dir_red,
+            "cls_pos_loss": cls_pos, "cls_neg_loss": cls_neg, "num_positives": (labels_t > 0).sum()}
+
+
+def training_loss(second_cfg, box_preds, cls_preds, dir_cls_preds, labels, reg_targets, anchors, dtype=torch.float32):
+    """box_preds [B,H,W,na*7], cls_preds [B,H,W,na], dir_cls_preds [B,H,W,na*2] (numpy), labels [B,A] int,
+    reg_targets [B,A,7], anchors [A,7].  Returns (dict of python floats, dict of numpy gradients)."""
+    box = torch.tensor(np.asarray(box_preds), dtype=dtype, requires_grad=True)
+    cls = torch.tensor(np.asarray(cls_preds), dtype=dtype, requires_grad=True)
+    dr = torch.tensor(np.asarray(dir_cls_preds), dtype=dtype, requires_grad=True)
+    t = loss_tensors(second_cfg, box, cls, dr, labels, reg_targets, anchors, dtype)
+    t["loss"].backward()
+    vals = {k: float(v.detach()) for k, v in t.items() if k != "num_positives"}
+    vals["num_positives"] = int(t["num_positives"])
     grads = {"box_preds_grad": box.grad.numpy(), "cls_preds_grad": cls.grad.numpy(),
              "dir_cls_preds_grad": dr.grad.numpy() if dr.grad is not None else np.zeros_like(np.asarray(dir_cls_preds))}
     return vals, grads

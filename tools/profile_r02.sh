@@ -5,11 +5,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${TAG:-r02}
 O=gpurun_out/$TAG
 mkdir -p $O
-# kernel trace, ONE batch in flight (what roofline.frac is computed from), then the default three in flight
+# kernel trace, ONE batch in flight (what roofline.frac is computed from), then the default two in flight
 rocprofv3 --kernel-trace --stats -d $O/st1 -o b1 --output-format csv -- python3 bench.py --plain --inflight 1 --steps 200 > $O/plain_inflight1_line.json 2> $O/st1.log
 cp $(find $O/st1 -name "*kernel_stats.csv" | head -1) $O/${TAG}_inflight1_kernel_stats.csv
-rocprofv3 --kernel-trace --stats -d $O/st3 -o b3 --output-format csv -- python3 bench.py --plain --steps 200 > $O/plain_inflight3_line.json 2> $O/st3.log
-cp $(find $O/st3 -name "*kernel_stats.csv" | head -1) $O/${TAG}_inflight3_kernel_stats.csv
+rocprofv3 --kernel-trace --stats -d $O/st3 -o b3 --output-format csv -- python3 bench.py --plain --steps 200 > $O/plain_inflight2_line.json 2> $O/st3.log
+cp $(find $O/st3 -name "*kernel_stats.csv" | head -1) $O/${TAG}_inflight2_kernel_stats.csv
 echo "kernel-trace passes done"
 # HBM traffic: separate --pmc passes (FETCH_SIZE, WRITE_SIZE), one batch in flight
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_f -o pmc --output-format csv -- python3 bench.py --plain --steps 4 --warmup 1 --inflight 1 > $O/pmc_f.log 2>&1
