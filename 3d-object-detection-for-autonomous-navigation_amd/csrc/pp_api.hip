@@ -117,6 +117,12 @@ struct pp_engine {
         int64_t n_params = 0, n_state = 0;
         TrainCtx cx;
         bool buffers = false;
+        // the ~250 launches of a step replay as one hipGraph while nothing they depend on changes
+        hipGraphExec_t graph = nullptr;
+        int g_batch = -1, g_bucket = -1, g_buf = -1;
+        const void *g_params = nullptr, *g_grads = nullptr, *g_state = nullptr;
+        pp_loss_config g_loss;
+        int graph_state = 0;   // -1: capture failed once, plain launches from then on
     };
     TrainState* train = nullptr;
 
@@ -218,7 +224,8 @@ namespace {
 struct ProfScope {
     pp_engine* e;
     int e1 = -1;
-    ProfScope(pp_engine* en, const char* name, bool bracket = false) : e(en) {
+    PpProf saved;          // scopes nest (pp_train_step wraps the voxeliser's named scopes)
+    ProfScope(pp_engine* en, const char* name, bool bracket = false) : e(en), saved(g_pp_prof) {
         if (e->prof <= 0) return;
         if (bracket) {
             int e0 = prof_event(e);
@@ -233,8 +240,7 @@ struct ProfScope {
     }
     ~ProfScope() {
         if (e1 >= 0) (void)hipEventRecord(e->events[e1], e->stream);
-        g_pp_prof.e = nullptr;
-        g_pp_prof.tag = nullptr;
+        g_pp_prof = saved;
     }
 };
 
@@ -751,6 +757,7 @@ int pp_destroy(pp_handle e) {
     graph_invalidate(e);
     for (void* p : e->allocs) (void)hipFree(p);
     for (void* p : e->wallocs) (void)hipFree(p);
+    if (e->train && e->train->graph) (void)hipGraphExecDestroy(e->train->graph);
     delete e->train;
     if (e->h_off_ring) (void)hipHostFree(e->h_off_ring);
     for (hipEvent_t ev : e->off_ev) if (ev) (void)hipEventDestroy(ev);
@@ -1506,6 +1513,7 @@ int train_buffers(pp_engine* e) {
     A1(dalloc(e, &cx.pfn_arg, B * s.max_voxels * s.C));
     A1(dalloc(e, &cx.pfn_stats, (size_t)2 * s.C));
     A1(dalloc(e, &cx.pfn_sums, (size_t)2 * s.C));
+    A1(dalloc(e, &cx.pfn_nrows, (size_t)1));
     A1(dalloc(e, &cx.canvas, B * s.ny * s.nx * s.C));
     A1(dalloc(e, &cx.dcanvas, B * s.ny * s.nx * s.C));
     size_t max_z = 1, max_d = 1;
@@ -1610,15 +1618,8 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
         e->up_pending = false;
     }
     prof_reset(e);
-    if ((st = run_voxelize(e, batch, e->cur_max_n))) return st;
-    std::vector<int> np((size_t)batch);
-    HIPCHK(e, hipMemcpyAsync(np.data(), e->d_npillars, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->d_loss_labels, labels, (size_t)batch * e->A * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->d_loss_regt, reg_targets, (size_t)batch * e->A * 7 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    long total_p = 0;
-    for (int v : np) total_p += v;
-    if (total_p < 1) return fail(e, PP_ERR_ARG, "pp_train_step: the batch has no pillar");
     pp_engine::TrainState* t = e->train;
     TrainCtx& cx = t->cx;
     cx.stream = e->stream;
@@ -1627,9 +1628,50 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
     cx.head = e->d_head; cx.dhead = e->d_head_grad;
     LossParams lp;
     fill_loss_params(e, lc, batch, lp);
-    {
+    auto enqueue = [&](int max_n) -> int {
+        int r = run_voxelize(e, batch, max_n);
+        if (r) return r;
+        return train_step(cx, t->shape, t->layout, params_dev, grads_dev, state_dev, batch, lp);
+    };
+    bool launched = false;
+    if (e->prof <= 0 && t->graph_state == 0 && graphs_enabled()) {
+        const int bucket = graph_bucket(e, e->cur_max_n);
+        const bool hit = t->graph != nullptr && t->g_batch == batch && t->g_bucket == bucket && t->g_buf == e->in_buf &&
+                         t->g_params == params_dev && t->g_grads == grads_dev && t->g_state == state_dev &&
+                         memcmp(&t->g_loss, lc, sizeof(pp_loss_config)) == 0;
+        if (!hit) {
+            if (t->graph) {
+                HIPCHK(e, hipStreamSynchronize(e->stream));
+                (void)hipGraphExecDestroy(t->graph);
+                t->graph = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            st = ok ? enqueue(bucket) : PP_ERR_HIP;
+            if (ok && hipStreamEndCapture(e->stream, &g) != hipSuccess) { ok = false; g = nullptr; }
+            if (ok && st == PP_ERR_UNSUPPORTED) {
+                if (g) (void)hipGraphDestroy(g);
+                return fail(e, st, "pp_train_step: configuration not supported by the training kernels");
+            }
+            if (ok && st == PP_OK && g != nullptr && hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0) == hipSuccess) {
+                t->g_batch = batch; t->g_bucket = bucket; t->g_buf = e->in_buf;
+                t->g_params = params_dev; t->g_grads = grads_dev; t->g_state = state_dev; t->g_loss = *lc;
+            } else {
+                t->graph = nullptr;
+                t->graph_state = -1;
+                (void)hipGetLastError();
+            }
+            if (g) (void)hipGraphDestroy(g);
+        }
+        if (t->graph != nullptr) {
+            HIPCHK(e, hipGraphLaunch(t->graph, e->stream));
+            launched = true;
+            st = PP_OK;
+        }
+    }
+    if (!launched) {
         ProfScope ps(e, nullptr);
-        st = train_step(cx, t->shape, t->layout, params_dev, grads_dev, state_dev, batch, (int)total_p, lp);
+        st = enqueue(e->cur_max_n);
     }
     if (st) return fail(e, st, "pp_train_step: configuration not supported by the training kernels");
     HIPCHK(e, hipGetLastError());

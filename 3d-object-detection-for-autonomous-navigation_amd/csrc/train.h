@@ -44,6 +44,7 @@ struct TrainCtx {
     int* pfn_arg;        // [B * max_voxels][C]
     float* pfn_stats;    // [C][2]
     float* pfn_sums;     // [2][C]
+    float* pfn_nrows;    // [1] rows of the padded PFN tensor (pillars of the batch * T), computed on the device
     float* canvas;       // [B][ny][nx][C]
     float* dcanvas;
     // RPN
@@ -67,4 +68,4 @@ std::vector<TrainEntry> train_layout(const TrainShape& s, int64_t* n_params, int
 size_t train_part_floats(const TrainShape& s);
 // forward (training mode) + loss + backward for `batch` resident, voxelised frames; grads overwritten, state updated
 int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainEntry>& layout, const float* params,
-               float* grads, float* state, int batch, int total_pillars, const LossParams& loss);
+               float* grads, float* state, int batch, const LossParams& loss);

@@ -36,7 +36,7 @@
 typedef float tf32x16 __attribute__((ext_vector_type(16)));
 
 #define TR_EPS 1e-3f
-#define TR_NPART 512   // workgroups of the persistent reduction kernels (= rows of their partial-sum buffers)
+#define TR_NPART 256   // workgroups of the persistent reduction kernels (= rows of their partial-sum buffers)
 
 // ------------------------------------------------------------------------------------------------------------
 // float32 MFMA GEMM:  C[M][N] (+)= A(m,k) * B(k,n) [+ bias(n)],  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
@@ -119,18 +119,25 @@ __global__ __launch_bounds__(256) void k_tr_gemm(TGemm g) {
     }
 }
 
-// out[i] (+)= scale * sum_p part[p][i], parts added in index order (deterministic)
+// out[i] (+)= scale * sum_p part[p][i] in a fixed order (deterministic): 16 lanes share an output element, lane l
+// adds parts l, l + 16, ... and the 16 lane sums are added by a shuffle tree
 __global__ __launch_bounds__(256) void k_tr_reduce(const float* __restrict__ part, int nparts, long n, long pstride,
                                                    float* __restrict__ out, long ldo, int ncols, int accumulate, float scale) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int l = threadIdx.x & 15;
+    const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * pstride + i];
+    if (i < n)
+        for (int p = l; p < nparts; p += 16) s += part[(size_t)p * pstride + i];
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (i >= n || l != 0) return;
     s *= scale;
     // optional re-striding of the output ([rows][ncols] with leading dimension ldo)
     float* o = (ncols > 0) ? out + (i / ncols) * ldo + (i % ncols) : out + i;
     *o = accumulate ? (*o + s) : s;
 }
+
+static unsigned reduce_blocks(long n) { return (unsigned)((n + 15) / 16); }
 
 static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
                     long ldc, int M, int N, int K, const float* bias, int accumulate, int ksplit) {
@@ -145,7 +152,7 @@ static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, cons
     PP_LAUNCH("k_tr_gemm", k_tr_gemm, grid, dim3(256), 0, cx.stream, g);
     if (ksplit > 1) {
         const long n = (long)M * N;
-        PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cx.stream,
+        PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(n)), dim3(256), 0, cx.stream,
                   (const float*)cx.gemm_part, ksplit, n, n, C, ldc, N, accumulate, 1.0f);
     }
 }
@@ -295,11 +302,13 @@ __global__ __launch_bounds__(256) void k_tr_colstats(const float* __restrict__ Z
 }
 
 // sums[0][c], sums[1][c] -> stats[c] = (mean, 1/sqrt(var + eps)); moving statistics updated in place
-__global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict__ sums, int C, float n_rows, float momentum,
+__global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict__ sums, int C, float n_rows_arg,
+                                                        const float* __restrict__ n_rows_dev, float momentum,
                                                         int unbiased_moving, float* __restrict__ stats,
                                                         float* __restrict__ moving_mean, float* __restrict__ moving_var) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    const float n_rows = fmaxf((n_rows_dev != nullptr) ? *n_rows_dev : n_rows_arg, 1.f);   // PFN: P * T, known on the device only
     const float mean = sums[c] / n_rows;
     float var = sums[C + c] / n_rows - mean * mean;
     var = fmaxf(var, 0.f);
@@ -600,7 +609,7 @@ template <int CPL>
 __global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* __restrict__ Y, const float* __restrict__ stats,
                                                           const float* __restrict__ gamma, const int* __restrict__ arg,
                                                           const float* __restrict__ dcanvas, const float* __restrict__ sums,
-                                                          float n_rows, float* __restrict__ part) {
+                                                          const float* __restrict__ n_rows_dev, float* __restrict__ part) {
     __shared__ float sp[4][10][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
@@ -609,6 +618,7 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* _
     for (int k = 0; k < 10; ++k)
 #pragma unroll
         for (int q = 0; q < CPL; ++q) dw[k][q] = 0.f;
+    const float n_rows = fmaxf(*n_rows_dev, 1.f);
     float mean[CPL], inv[CPL], gi[CPL], m1[CPL], m2[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
@@ -756,7 +766,7 @@ struct Lookup {
 unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
 
 void col_reduce(const TrainCtx& cx, int C, float* sums) {   // TR_NPART partial rows of [2][C] -> sums[2][C]
-    PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(blocks_for(2 * C)), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
+    PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(2 * C)), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
               (long)2 * C, (long)2 * C, sums, 0L, 0, 0, 1.0f);
 }
 
@@ -767,7 +777,7 @@ void bn_relu_forward(const TrainCtx& cx, const float* Z, long rows, int C, const
     PP_LAUNCH("k_tr_colstats", k_tr_colstats, dim3(TR_NPART), dim3(256), 0, cx.stream, Z, rows, C, cx.part);
     col_reduce(cx, C, sums);
     PP_LAUNCH("k_tr_bn_finalize", k_tr_bn_finalize, dim3((C + 255) / 256), dim3(256), 0, cx.stream, (const float*)sums, C,
-              (float)rows, momentum, 1, stats, mmean, mvar);
+              (float)rows, (const float*)nullptr, momentum, 1, stats, mmean, mvar);
     PP_LAUNCH("k_tr_bn_relu", k_tr_bn_relu, dim3(blocks_for(rows * (C / 4))), dim3(256), 0, cx.stream, Z, rows, C,
               (const float*)stats, gamma, beta, A, ld, co_off, rm);
 }
@@ -785,28 +795,38 @@ void bn_relu_backward(const TrainCtx& cx, const float* dA, int ld, int co_off, R
               Z, rows, C, stats, gamma, beta, (const float*)sums, (float)rows, dZ);
 }
 
+// n_rows[0] = (sum of the frames' pillar counts) * T: the rows of the reference's padded [P, T, C] tensor
+__global__ void k_tr_pfn_rows(const int* __restrict__ npillars, int batch, int T, float* __restrict__ n_rows) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        long tot = 0;
+        for (int b = 0; b < batch; ++b) tot += npillars[b];
+        n_rows[0] = (float)tot * (float)T;
+    }
+}
+
 template <int CPL>
-void pfn_forward(const TrainCtx& cx, const PfnT& p, const Lookup& L, float n_rows) {
+void pfn_forward(const TrainCtx& cx, const PfnT& p, const Lookup& L) {
+    PP_LAUNCH("k_tr_pfn_rows", k_tr_pfn_rows, dim3(1), dim3(64), 0, cx.stream, p.npillars, p.batch, p.T, cx.pfn_nrows);
     PP_LAUNCH("k_tr_pfn_lin", (k_tr_pfn_lin<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, cx.pfn_y, cx.part);
     col_reduce(cx, p.C, cx.pfn_sums);
     PP_LAUNCH("k_tr_bn_finalize", k_tr_bn_finalize, dim3((p.C + 255) / 256), dim3(256), 0, cx.stream, (const float*)cx.pfn_sums,
-              p.C, n_rows, 0.01f, 0, cx.pfn_stats, L.s("pfn/bn/moving_mean"), L.s("pfn/bn/moving_variance"));
+              p.C, 0.f, (const float*)cx.pfn_nrows, 0.01f, 0, cx.pfn_stats, L.s("pfn/bn/moving_mean"), L.s("pfn/bn/moving_variance"));
     PP_LAUNCH("k_tr_pfn_max", (k_tr_pfn_max<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, (const float*)cx.pfn_y,
               (const float*)cx.pfn_stats, L.p("pfn/bn/gamma"), L.p("pfn/bn/beta"), cx.pfn_feat, cx.pfn_arg);
 }
 
 template <int CPL>
-void pfn_backward(const TrainCtx& cx, const PfnT& p, const Lookup& L, float n_rows, const float* dcanvas) {
+void pfn_backward(const TrainCtx& cx, const PfnT& p, const Lookup& L, const float* dcanvas) {
     PP_LAUNCH("k_tr_pfn_bwd_reduce", (k_tr_pfn_bwd_reduce<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p,
               (const float*)cx.pfn_y, (const float*)cx.pfn_stats, (const int*)cx.pfn_arg, dcanvas, cx.part);
     col_reduce(cx, p.C, cx.pfn_sums);
     (void)hipMemcpyAsync(L.g("pfn/bn/beta"), cx.pfn_sums, (size_t)p.C * sizeof(float), hipMemcpyDeviceToDevice, cx.stream);
     (void)hipMemcpyAsync(L.g("pfn/bn/gamma"), cx.pfn_sums + p.C, (size_t)p.C * sizeof(float), hipMemcpyDeviceToDevice, cx.stream);
     PP_LAUNCH("k_tr_pfn_bwd_apply", (k_tr_pfn_bwd_apply<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, (const float*)cx.pfn_y,
-              (const float*)cx.pfn_stats, L.p("pfn/bn/gamma"), (const int*)cx.pfn_arg, dcanvas, (const float*)cx.pfn_sums, n_rows,
-              cx.part);
+              (const float*)cx.pfn_stats, L.p("pfn/bn/gamma"), (const int*)cx.pfn_arg, dcanvas, (const float*)cx.pfn_sums,
+              (const float*)cx.pfn_nrows, cx.part);
     const long n = (long)p.FA * p.C;
-    PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(blocks_for(n)), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART, n, n,
+    PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(n)), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART, n, n,
               L.g("pfn/dense/kernel"), 0L, 0, 0, 1.0f);
 }
 
@@ -820,7 +840,7 @@ size_t train_part_floats(const TrainShape& s) {
 }
 
 int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainEntry>& layout, const float* params,
-               float* grads, float* state, int batch, int total_pillars, const LossParams& loss_in) {
+               float* grads, float* state, int batch, const LossParams& loss_in) {
     Lookup L{layout, params, grads, state};
     const int B = batch;
     if (s.C > 256 || s.C % 4 != 0 || s.FA > 10) return PP_ERR_UNSUPPORTED;
@@ -837,11 +857,10 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
     p.vx = s.vx; p.vy = s.vy; p.x_off = s.x_off; p.y_off = s.y_off;
     p.pts_sorted = cx.pts_sorted; p.offsets = cx.offsets; p.pillar_start = cx.pillar_start; p.pillar_cell = cx.pillar_cell;
     p.npillars = cx.npillars; p.W = L.p("pfn/dense/kernel");
-    const float pfn_rows = (float)total_pillars * (float)s.T;    // all P * T rows of the reference's padded tensor
     const int cpl = (s.C + 63) / 64;
-    if (cpl == 1) pfn_forward<1>(cx, p, L, pfn_rows);
-    else if (cpl == 2) pfn_forward<2>(cx, p, L, pfn_rows);
-    else pfn_forward<4>(cx, p, L, pfn_rows);
+    if (cpl == 1) pfn_forward<1>(cx, p, L);
+    else if (cpl == 2) pfn_forward<2>(cx, p, L);
+    else pfn_forward<4>(cx, p, L);
     const int ncanvas = s.nx * s.ny;
     PP_LAUNCH("k_tr_scatter", k_tr_scatter, dim3(blocks_for((long)B * ncanvas * (s.C / 4))), dim3(256), 0, cx.stream, cx.cellmap,
               (const float*)cx.pfn_feat, cx.canvas, B, s.nz, ncanvas, s.C, s.max_voxels);
@@ -956,7 +975,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                       l.in_h, l.in_w, l.out_h, l.out_w, l.cin, l.stride);
             {
                 const long n = (long)9 * l.cin;
-                PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(blocks_for(n)), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
+                PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(n)), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
                           n, n, L.g(pre + "/depthwise_kernel"), 0L, 0, 0, 1.0f);
             }
             // gradient of this layer's input: the previous layer's dA, the previous block's output gradient, or the canvas
@@ -967,8 +986,8 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
         }
     }
     // canvas -> pillar features -> PFN
-    if (cpl == 1) pfn_backward<1>(cx, p, L, pfn_rows, cx.dcanvas);
-    else if (cpl == 2) pfn_backward<2>(cx, p, L, pfn_rows, cx.dcanvas);
-    else pfn_backward<4>(cx, p, L, pfn_rows, cx.dcanvas);
+    if (cpl == 1) pfn_backward<1>(cx, p, L, cx.dcanvas);
+    else if (cpl == 2) pfn_backward<2>(cx, p, L, cx.dcanvas);
+    else pfn_backward<4>(cx, p, L, cx.dcanvas);
     return PP_OK;
 }

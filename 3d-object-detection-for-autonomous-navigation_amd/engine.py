@@ -303,7 +303,7 @@ class Engine:
         self._check(self._lib.pp_set_profiling(self._h, 1 if on else 0), "pp_set_profiling")
 
     def kernel_times(self):
-        cap = 128
+        cap = 2048
         names = (ctypes.c_char_p * cap)()
         ms = (ctypes.c_float * cap)()
         n = ctypes.c_int32(0)

@@ -9,13 +9,20 @@ Mirror of model/voxelnet.py::VoxelNet for the eval path (train.py:575-771):
 Trv2c, P2, anchors, anchors_mask, image_idx, image_shape); elements may be
 numpy arrays or anything with `.numpy()` (the reference passes TF tensors).
 `detect(frames, ...)` is the fused raw-points path the reference does not have.
-Training (training=True, labels/reg_targets) is out of scope and raises.
+
+Training mode (model/voxelnet.py:922-1049 + train.py:265-304), `VoxelNet(config, writer, training=True)`:
+    ret = net(voxels, num_points, coors, batch_anchors, labels, reg_targets)   # the reference's loss dict (scalars)
+    net.apply_gradients(dist=None)        # optimizer.apply_gradients: one all-reduce over the ranks + AdamW
+or, from raw clouds, `net.train_step(frames, labels, reg_targets, dist)`.  The forward pass, the loss and the
+gradients of a call come from one `pp_train_step` (csrc/train.hip); the padded voxel tensor is unpadded on the
+host into the pillar-ordered point list it was built from (the voxeliser then reproduces the same pillars).
 """
 import numpy as np
 
 from . import weights as _weights
 from .config import Derived
 from .engine import Engine
+from .trainer import Trainer
 
 
 def _np(x):
@@ -24,31 +31,75 @@ def _np(x):
 
 class VoxelNet:
     def __init__(self, config, writer=None, training=False, max_batch=None, max_points_per_frame=32768, device=0):
-        if training:
-            raise NotImplementedError("only the inference path (training=False) is built (SURVEY section 8 scope)")
         self.config = config
-        self.training = False
+        self.training = bool(training)
         self.d = Derived(config)
         self.batch_size = self.d.batch_size
-        self.engine = Engine(self.d, max_batch=max_batch or self.batch_size,
-                             max_points_per_frame=max_points_per_frame, device=device)
         self.box_code_size = 7
+        self.trainer = None
+        self._ctor = dict(max_batch=max_batch or self.batch_size, max_points_per_frame=max_points_per_frame, device=device)
+        if self.training:
+            self.engine = None      # the Trainer (created by load_weights: it needs initial values) owns the engine
+        else:
+            self.engine = Engine(self.d, **self._ctor)
 
     # net.load_weights (train.py:731-734).  Accepts a dict name -> array (Keras
     # layouts, weights.py) or an .npz written by weights.save_npz.
     def load_weights(self, src):
         w = _weights.load_npz(src) if isinstance(src, str) else src
+        if self.training:
+            if self.trainer is None:
+                self.trainer = Trainer(self.config, w, **self._ctor)
+                self.engine = self.trainer.engine
+            else:
+                self.trainer.set_weights(w)
+            return
         self.engine.load_weights(w)
 
     def __call__(self, voxels, num_points, coors, batch_anchors, labels=None, reg_targets=None):
+        if self.training:
+            if labels is None or reg_targets is None:
+                raise ValueError("training mode needs labels and reg_targets (model/voxelnet.py:850)")
+            return self.train_step(self._unpad(_np(voxels), _np(num_points), _np(coors), int(_np(batch_anchors).shape[0])),
+                                   _np(labels), _np(reg_targets), apply=False)
         if labels is not None or reg_targets is not None:
-            raise NotImplementedError("training branch (labels / reg_targets) is out of scope")
+            raise ValueError("labels / reg_targets are training inputs: build the net with training=True")
         if not self.engine.weights_loaded:
             raise RuntimeError("VoxelNet: load_weights() has not been called")
         batch = int(_np(batch_anchors).shape[0])
         return self.engine.forward_voxels(_np(voxels), _np(num_points), _np(coors), batch)
 
     call = __call__
+
+    # ---- training mode ----
+    @staticmethod
+    def _unpad(voxels, num_points, coors, batch):
+        """Padded [P,T,F] + num_points + coors[b,z,y,x] -> per-frame point lists in pillar order."""
+        frames = []
+        for b in range(batch):
+            rows = np.nonzero(coors[:, 0] == b)[0]
+            frames.append(np.concatenate([voxels[p, :num_points[p]] for p in rows], axis=0).astype(np.float32)
+                          if len(rows) else np.zeros((0, voxels.shape[2]), np.float32))
+        return frames
+
+    def train_step(self, frames, labels, reg_targets, dist=None, apply=True):
+        """Forward (training mode) + loss + backward on raw clouds; apply=True also runs the optimizer step.
+        Returns the reference's loss scalars (model/voxelnet.py:1032-1043)."""
+        if self.trainer is None:
+            raise RuntimeError("VoxelNet(training=True): load_weights() with the initial values first")
+        out = self.trainer.forward_backward(frames, labels, reg_targets)
+        if apply:
+            self.apply_gradients(dist)
+        return out
+
+    def apply_gradients(self, dist=None):
+        """optimizer.apply_gradients (train.py:301) on the flat buffers, after the data-parallel all-reduce."""
+        from . import optim
+        optim.allreduce_gradients(self.trainer.grads, dist)
+        self.trainer.optimizer.apply_gradients(self.trainer.grads)
+
+    def get_weights(self):
+        return self.trainer.weights() if self.training else None
 
     def predict(self, example, preds_dict):
         rect, trv2c = _np(example[3]), _np(example[4])

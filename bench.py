@@ -331,6 +331,76 @@ def cfgk_leg(pp, local_rank, steps=12):
     return out
 
 
+def train_gemm_flops(d, batch):
+    """Algorithmic FLOPs of the GEMM-shaped work of one training step: the forward products of the pointwise, the
+    transposed-convolution and the head layers, times three (forward, input gradient, weight gradient)."""
+    lf = layer_flops(d, batch, heads_fused=False)
+    fwd = 0.0
+    h, w, cin = d.ny, d.nx, d.pfn_filters
+    for b in range(3):
+        cout = d.num_filters[b]
+        for j in range(d.layer_nums[b] + 1):
+            s_ = d.layer_strides[b] if j == 0 else 1
+            h, w = (h + 2 - 3) // s_ + 1, (w + 2 - 3) // s_ + 1
+            fwd += 2.0 * batch * h * w * cin * cout
+            cin = cout
+        fwd += lf[f"deconv{b + 1}"]
+    fwd += 2.0 * batch * d.head_h * d.head_w * d.concat_channels * 32     # the packed 32-column head GEMM
+    return 3.0 * fwd
+
+
+def train_leg(pp, local_rank, rank, n_gpus, dist, comm_dev, barrier, steps=20, batch=2):
+    """BASELINE.json configs[4]: one optimizer step = upload + voxelise + training-mode forward + loss + backward
+    (pp_train_step) + ONE all-reduce of the flat 4.4 MB gradient buffer over the ranks + AdamW, at the reference's
+    training batch (2 frames per GPU, configs/train.yaml:62), cfg-A, synthetic clouds and targets."""
+    import torch
+    cfg = pp.config.pedestrian_d435i_config(batch)
+    d = pp.config.Derived(cfg)
+    tr = pp.Trainer(cfg, pp.weights.init_weights(d, seed=7), max_batch=batch, max_points_per_frame=16384, device=local_rank,
+                    learning_rate=2e-4, weight_decay=1e-4)
+    rng = np.random.default_rng(50 + rank)
+    frames = [pp.synth.d435i_cloud(5000 + rank * batch + i, 16384) for i in range(batch)]
+    labels = rng.choice([-1, 0, 0, 0, 0], size=(batch, d.num_anchors)).astype(np.int32)
+    reg = np.zeros((batch, d.num_anchors, 7), np.float32)
+    for b in range(batch):
+        pos = rng.choice(d.num_anchors, 30, replace=False)
+        labels[b, pos] = 1
+        reg[b, pos] = rng.normal(0, 0.4, (30, 7)).astype(np.float32)
+    for _ in range(3):
+        out = tr.step(frames, labels, reg, dist)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.step(frames, labels, reg, dist)
+    barrier()
+    el = pp.frame_shard.max_over_ranks(time.perf_counter() - t0, dist, comm_dev)
+    res = {"workload": f"cfg-A training step, {batch} frames/GPU x 16384 pts, {tr.params.numel()} trainable parameters "
+                       f"({tr.params.numel() * 4 / 1e6:.1f} MB gradient all-reduce per step)",
+           "n_gpus": n_gpus, "steps": steps, "ms_per_step": el / steps * 1e3, "steps_per_s": steps / el,
+           "samples_per_s": n_gpus * batch * steps / el, "last_loss": out["loss"]}
+    if rank == 0:
+        tr.engine.set_profiling(True)
+        tr.forward_backward(frames, labels, reg)
+        agg = {}
+        for name, ms in tr.engine.kernel_times():
+            a = agg.setdefault(name.split(":")[0], [0.0, 0])
+            a[0] += ms
+            a[1] += 1
+        tr.engine.set_profiling(False)
+        res["kernel_ms_per_step"] = {k: round(v[0], 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+        res["kernel_launches_per_step"] = {k: v[1] for k, v in agg.items()}
+        res["sum_kernel_ms_per_step"] = sum(v[0] for v in agg.values())
+        if "k_tr_gemm" in agg:
+            fl = train_gemm_flops(d, batch)
+            t = agg["k_tr_gemm"][0] * 1e-3
+            res["roofline"] = {"bound": "mfma", "kernel": "k_tr_gemm", "achieved": fl / t / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": fl / t / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "algorithmic_flops_per_step": fl, "launches_per_step": agg["k_tr_gemm"][1],
+                               "ms_per_step": agg["k_tr_gemm"][0], "mfma_roof": "f32 MFMA (v_mfma_f32_32x32x2_f32)"}
+    tr.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,6 +418,7 @@ def main():
                          "run rocprofv3 wraps for profiles/*_kernel_stats.csv, one regime per file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfgk", action="store_true", help="skip the KITTI-shaped B=32 leg (detail.cfgK)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (detail.train, configs[4])")
     ap.add_argument("--latency-b1", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-latency-b1", action="store_true", help="skip the batch-1 latency leg")
     args = ap.parse_args()
@@ -540,6 +611,14 @@ def main():
             extras["cfgK"] = cfgk_leg(pp, local_rank)
         except Exception as ex:   # the leg must not take the headline line down with it
             extras["cfgK"] = {"error": repr(ex)}
+
+    if not args.no_train:      # every rank takes part: the step ends in an all-reduce over the ranks
+        try:
+            extras["train"] = train_leg(pp, local_rank, rank, n_gpus, dist, comm_dev, barrier)
+        except Exception as ex:
+            if dist is not None:
+                raise
+            extras["train"] = {"error": repr(ex)}
 
     cpu = None
     if want_cpu:

@@ -221,3 +221,30 @@ def test_two_rank_data_parallel_step(hip_lib, tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_voxelnet_training_call_surface(pp, hip_lib):
+    """VoxelNet(config, writer, training=True)(voxels, num_points, coors, anchors, labels, reg_targets): the
+    reference's call with the dataloader's padded tensors gives the same loss and gradients as the raw-cloud path."""
+    B = 2
+    cfg = pp.config.tiny_config(B)
+    rng = np.random.default_rng(23)
+    frames = [rng.uniform([0, -0.64, -3], [1.6, 0.64, 3], (n, 3)).astype(np.float32) for n in (800, 350)]
+    d, labels, reg = _problem(pp, cfg, frames, 5, npos=10)
+    w = pp.weights.init_weights(d, seed=6)
+    net = pp.VoxelNet(cfg, None, training=True, max_batch=B, max_points_per_frame=4096)
+    with pytest.raises(RuntimeError):
+        net.train_step(frames, labels, reg)
+    net.load_weights(w)
+    a = net.train_step(frames, labels, reg, apply=False)
+    ga = net.trainer.grads.cpu().numpy().copy()
+    rect, trv, p2 = pp.synth.default_calib()
+    ex, _ = util_ref.oracle_example(d, frames, rect, trv, p2)
+    b = net(ex[0], ex[1], ex[2], ex[6], labels, reg)
+    assert a["loss"] == b["loss"] and np.array_equal(net.trainer.grads.cpu().numpy(), ga)
+    before = net.trainer.params.cpu().numpy().copy()
+    net.apply_gradients()
+    assert np.abs(net.trainer.params.cpu().numpy() - before).max() > 0
+    with pytest.raises(ValueError):
+        net(ex[0], ex[1], ex[2], ex[6])
+    net.trainer.close()
