@@ -119,3 +119,72 @@ def save_npz(path, w):
 def load_npz(path):
     with np.load(path) as z:
         return {k.replace(".", "/"): np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Keras .h5 checkpoints (net.save_weights / net.load_weights, train.py:407,436,731-734)
+# ---------------------------------------------------------------------------------------------------------
+_KINDS = ("depthwise_kernel", "pointwise_kernel", "gamma", "beta", "moving_mean", "moving_variance", "kernel", "bias")
+
+
+def map_keras_weight_names(keras_names, d):
+    """Maps the variable names of a Keras checkpoint of the reference's VoxelNet to this package's tensor names.
+
+    The reference's model tree (train.py:62-113: net.layers = [loss, PillarFeatureNet, PointPillarsScatter, RPN];
+    PillarFeatureNet.layers[0] = Sequential(Dense, BatchNormalization "batch", ReLU); RPN.layers = [block1, deconv1,
+    block2, deconv2, block3, deconv3, conv_box, conv_cls, conv_dir_cls], the six Sequentials named "block1" ...
+    "deconv3", model/voxelnet.py:573-660) fixes where a variable lives; Keras numbers the anonymous layers inside
+    (separable_conv2d_7, batch_normalization_12, ...) by creation order.  The mapping therefore goes by the NAMED
+    path component (block{b} / deconv{b} / conv_box / conv_cls / conv_dir_cls, anything else with a Dense kernel or
+    the "batch" BatchNorm = the PFN), the variable kind (last path component) and the order of appearance of that
+    kind inside the component -- `layer.weights` lists a Sequential's variables in layer order (trainable first, then
+    the moving statistics, each in layer order).  Returns {package name: keras name}; shapes are checked by the caller.
+    """
+    counters = {}
+    out = {}
+    for kn in keras_names:
+        parts = kn.split(":")[0].split("/")
+        kind = parts[-1]
+        if kind not in _KINDS:
+            continue
+        comp = None
+        for tok in parts[:-1]:
+            if tok.startswith(("block", "deconv")) and tok[-1].isdigit() or tok in ("conv_box", "conv_cls", "conv_dir_cls"):
+                comp = tok
+        if comp is None:
+            comp = "pfn"
+        idx = counters.get((comp, kind), 0)
+        counters[(comp, kind)] = idx + 1
+        if comp == "pfn":
+            name = "pfn/dense/kernel" if kind == "kernel" else f"pfn/bn/{kind}"
+        elif comp.startswith("block"):
+            name = f"rpn/{comp}/{idx}/{kind}" if kind.endswith("_kernel") else f"rpn/{comp}/{idx}/bn/{kind}"
+        elif comp.startswith("deconv"):
+            name = f"rpn/{comp}/kernel" if kind == "kernel" else f"rpn/{comp}/bn/{kind}"
+        else:
+            name = f"rpn/{comp}/{kind}"
+        if name in out:
+            raise ValueError(f"two checkpoint variables map to {name!r}: {out[name]!r} and {kn!r}")
+        out[name] = kn
+    missing = [n for n in expected_shapes(d) if n not in out]
+    if missing:
+        raise ValueError(f"checkpoint lacks {len(missing)} tensors, e.g. {missing[:3]}")
+    return out
+
+
+def from_keras_h5(group, d):
+    """`group`: an open h5py.File of a Keras `save_weights` checkpoint (root attribute `layer_names`, one group per
+    top-level layer with the attribute `weight_names` and one dataset per variable) -- or any object with the same
+    mapping interface (the unit test uses plain dicts).  Returns this package's weight dict, shapes verified."""
+    def _s(x):
+        return x.decode() if isinstance(x, bytes) else str(x)
+    names, data = [], {}
+    for ln in group.attrs["layer_names"]:
+        g = group[_s(ln)]
+        for wn in g.attrs.get("weight_names", []):
+            names.append(_s(wn))
+            data[_s(wn)] = np.asarray(g[_s(wn)], dtype=np.float32)
+    mapping = map_keras_weight_names(names, d)
+    w = {name: np.ascontiguousarray(data[kn]) for name, kn in mapping.items() if name in expected_shapes(d)}
+    check_weights(d, w)
+    return w

@@ -134,3 +134,75 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not pat.search(txt), os.path.join(dp, f)
+
+
+class _FakeGroup(dict):
+    """dict with an `.attrs` dict: the slice of the h5py interface weights.from_keras_h5 uses."""
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.attrs = {}
+
+
+def _fake_keras_checkpoint(pp, d, w):
+    """The variable list Keras 2.3 / TF 2.2 writes for the reference's model tree: anonymous layers numbered by
+    creation order, per top-level layer the trainable variables in layer order, then the moving statistics."""
+    root = _FakeGroup()
+    root.attrs["layer_names"] = [b"weighted_smooth_l1_localization_loss", b"pillar_feature_net", b"point_pillars_scatter", b"rpn"]
+    root["weighted_smooth_l1_localization_loss"] = _FakeGroup()
+    root["point_pillars_scatter"] = _FakeGroup()
+    pfn = _FakeGroup()
+    pn = "voxel_net/pillar_feature_net/sequential/"
+    pairs = [(pn + "dense/kernel:0", "pfn/dense/kernel"), (pn + "batch/gamma:0", "pfn/bn/gamma"), (pn + "batch/beta:0", "pfn/bn/beta"),
+             (pn + "batch/moving_mean:0", "pfn/bn/moving_mean"), (pn + "batch/moving_variance:0", "pfn/bn/moving_variance")]
+    pfn.attrs["weight_names"] = [k.encode() for k, _ in pairs]
+    for k, ours in pairs:
+        pfn[k] = w[ours]
+    root["pillar_feature_net"] = pfn
+    rpn = _FakeGroup()
+    train, moving = [], []
+    n_sep = n_bn = n_dec = 0
+
+    def suffix(n):
+        return "" if n == 0 else f"_{n}"
+    for b in range(3):
+        for j in range(d.layer_nums[b] + 1):
+            base, ours = f"voxel_net/rpn/block{b + 1}/", f"rpn/block{b + 1}/{j}"
+            sep, bn = f"separable_conv2d{suffix(n_sep)}", f"batch_normalization{suffix(n_bn)}"
+            n_sep += 1
+            n_bn += 1
+            train += [(base + sep + "/depthwise_kernel:0", ours + "/depthwise_kernel"), (base + sep + "/pointwise_kernel:0", ours + "/pointwise_kernel"),
+                      (base + bn + "/gamma:0", ours + "/bn/gamma"), (base + bn + "/beta:0", ours + "/bn/beta")]
+            moving += [(base + bn + "/moving_mean:0", ours + "/bn/moving_mean"), (base + bn + "/moving_variance:0", ours + "/bn/moving_variance")]
+        # the reference builds deconv{b} right after block{b}; Keras lists RPN.layers in attribute order
+        base, ours = f"voxel_net/rpn/deconv{b + 1}/", f"rpn/deconv{b + 1}"
+        dec, bn = f"conv2d_transpose{suffix(n_dec)}", f"batch_normalization{suffix(n_bn)}"
+        n_dec += 1
+        n_bn += 1
+        train += [(base + dec + "/kernel:0", ours + "/kernel"), (base + bn + "/gamma:0", ours + "/bn/gamma"), (base + bn + "/beta:0", ours + "/bn/beta")]
+        moving += [(base + bn + "/moving_mean:0", ours + "/bn/moving_mean"), (base + bn + "/moving_variance:0", ours + "/bn/moving_variance")]
+    for hname in ("conv_box", "conv_cls", "conv_dir_cls"):
+        train += [(f"voxel_net/rpn/{hname}/kernel:0", f"rpn/{hname}/kernel"), (f"voxel_net/rpn/{hname}/bias:0", f"rpn/{hname}/bias")]
+    rpn.attrs["weight_names"] = [k.encode() for k, _ in train + moving]
+    for k, ours in train + moving:
+        rpn[k] = w[ours]
+    root["rpn"] = rpn
+    return root
+
+
+def test_keras_checkpoint_name_mapping(pp):
+    """f4: the .h5 importer's name / shape mapping on a synthetic checkpoint tree (h5py is absent here; the real
+    file is read with the same code through tools/h5_to_npz.py)."""
+    d = pp.config.Derived(pp.config.pedestrian_d435i_config())
+    w = pp.weights.init_weights(d, seed=13)
+    got = pp.weights.from_keras_h5(_fake_keras_checkpoint(pp, d, w), d)
+    assert set(got) == set(w) and all(np.array_equal(got[k], w[k]) for k in w)
+    broken = _fake_keras_checkpoint(pp, d, w)
+    names = broken["rpn"].attrs["weight_names"]
+    broken["rpn"].attrs["weight_names"] = [n for n in names if b"deconv2" not in n]
+    with pytest.raises(ValueError, match="lacks"):
+        pp.weights.from_keras_h5(broken, d)
+    swapped = _fake_keras_checkpoint(pp, d, w)
+    k0 = "voxel_net/rpn/block2/separable_conv2d_4/pointwise_kernel:0"
+    swapped["rpn"][k0] = swapped["rpn"][k0][..., :64]
+    with pytest.raises(ValueError, match="shape"):
+        pp.weights.from_keras_h5(swapped, d)
