@@ -1520,7 +1520,7 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
                 PC_PRODUCTS(acc[n], bh_, bm_, bl_, ah_, am_, al_)                                        \
             }                                                                                            \
         }                                                                                                \
-        if (i_ + 1 < total) D_STORE_B((i_ + 1) & 1)   /* weight tile of position i+1 -> LDS */          \
+        if (i_ + 1 < total && !(dbg & 512)) D_STORE_B((i_ + 1) & 1)   /* weight tile of position i+1 -> LDS */ \
         if (++mm_kc == nchunks) {                                                                        \
             deconv_tile_epilogue<NT>(a, acc, mm_tile, wave, lane, cbase, delta, s_opix[mm_slot], sHW, s_hbias);  \
             D_INIT_ACC()                                                                                 \
@@ -1531,10 +1531,11 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
             D_FILL_OPIX(mm_tile + GL, mm_slot ^ 1)   /* table of the next tile, one tile ahead */        \
         }                                                                                                \
         if (i_ + 1 < total) {   /* weight loads of position i+2 (after the epilogue: not live across it) */ \
-            if (i_ + 2 < total) D_LOAD_B(lb_kc)                                                          \
+            if (i_ + 2 < total && !(dbg & 512)) D_LOAD_B(lb_kc)                                          \
             if (++lb_kc == nchunks) lb_kc = 0;                                                           \
         }                                                                                                \
-        __syncthreads();                                                                                 \
+        /* tuning aid, bit 512: no weight staging and no barrier (wrong results): what resident weights could give */ \
+        if (!(dbg & 512)) __syncthreads();                                                               \
     }
     for (int i = 0; i < total; i += 2) {
         D_STEP(i, ra0, ra1)

@@ -1692,6 +1692,15 @@ int pp_adamw_step_device(int device, void* stream, float* params, const float* g
     return PP_OK;
 }
 
+int pp_device_mem_free(pp_handle e, int64_t* free_bytes) {
+    if (!e || !free_bytes) return PP_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    size_t fr = 0, tot = 0;
+    HIPCHK(e, hipMemGetInfo(&fr, &tot));
+    *free_bytes = (int64_t)fr;
+    return PP_OK;
+}
+
 int pp_device_info(pp_handle e, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes) {
     if (!e) return PP_ERR_ARG;
     hipDeviceProp_t prop;

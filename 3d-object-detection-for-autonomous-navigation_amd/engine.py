@@ -409,6 +409,11 @@ class Engine:
         self._check(self._lib.pp_timer_stop(self._h, ctypes.byref(t)), "pp_timer_stop")
         return float(t.value)
 
+    def device_mem_free(self):
+        v = ctypes.c_int64(0)
+        self._check(self._lib.pp_device_mem_free(self._h, ctypes.byref(v)), "pp_device_mem_free")
+        return v.value
+
     def device_info(self):
         name = ctypes.create_string_buffer(256)
         cu = ctypes.c_int32(0)

@@ -300,6 +300,8 @@ int pp_train_step(pp_handle h, const float* params_dev, float* grads_dev, float*
 
 /* Device properties for reports: name (<=255 chars), CU count, bytes of HBM. */
 int pp_device_info(pp_handle h, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes);
+/* Bytes of HBM currently free on the handle's device (hipMemGetInfo): leak checks, sizing. */
+int pp_device_mem_free(pp_handle h, int64_t* free_bytes);
 
 #ifdef __cplusplus
 }

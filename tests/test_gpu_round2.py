@@ -240,15 +240,14 @@ def test_graph_eviction_under_async_load(pp, hip_lib):
 
 
 def test_reloading_weights_does_not_leak(pp, hip_lib):
-    import torch
     eng = pp.Engine(pp.config.pedestrian_d435i_config(1), max_batch=1, max_points_per_frame=4096)
     w = pp.weights.init_weights(eng.d, seed=3)
     eng.load_weights(w)
     eng.load_weights(w)
-    free0 = torch.cuda.mem_get_info()[0]
+    free0 = eng.device_mem_free()
     for _ in range(20):
         eng.load_weights(w)
-    free1 = torch.cuda.mem_get_info()[0]
+    free1 = eng.device_mem_free()
     assert free0 - free1 < 4 << 20, f"{(free0 - free1) / 2**20:.1f} MiB lost over 20 reloads"
     # and the reloaded weights are live: different weights, different result
     frames = [pp.synth.d435i_cloud(5, 4096)]
