@@ -241,38 +241,46 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd_in(const float* __restrict__ 
     *dst = o;
 }
 
-// gradient of the depthwise kernel: part[blk][t][c] = sum over this workgroup's output pixels of X(window t) * dD
-// (thread = channel, workgroups stride over the pixels; k_tr_reduce adds the TR_NPART partials)
+// gradient of the depthwise kernel: part[blk][t][c] = sum over this workgroup's output pixels of X(window t) * dD.
+// 256 / C pixel lanes per workgroup (thread = channel x pixel lane), workgroups stride over the pixels;
+// k_tr_reduce adds the TR_NPART partial rows.
 __global__ __launch_bounds__(256) void k_tr_dw_bwd_w(const float* __restrict__ X, const float* __restrict__ dD,
                                                      float* __restrict__ part, int B, int ih, int iw, int oh, int ow,
                                                      int C, int S) {
+    __shared__ float sred[9 * 256];
     const int tid = threadIdx.x;
-    const int nc = (C + 255) / 256;   // channel rounds (C <= 256: one)
+    const int lanes_per_row = (C >= 256) ? 256 : C;      // C in {32, 64, 128, 256}
+    const int rsub = tid / lanes_per_row, nsub = 256 / lanes_per_row;
+    const int c = tid % lanes_per_row;
     const long npix = (long)B * oh * ow;
-    for (int r = 0; r < nc; ++r) {
-        const int c = tid + 256 * r;
-        float acc[9];
+    float acc[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-        if (c < C) {
-            for (long p = blockIdx.x; p < npix; p += gridDim.x) {
-                const int x = (int)(p % ow);
-                const int y = (int)((p / ow) % oh);
-                const int b = (int)(p / ((long)ow * oh));
-                const float g = dD[(size_t)p * C + c];
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (long p = (long)blockIdx.x * nsub + rsub; p < npix; p += (long)gridDim.x * nsub) {
+        const int x = (int)(p % ow);
+        const int y = (int)((p / ow) % oh);
+        const int b = (int)(p / ((long)ow * oh));
+        const float g = dD[(size_t)p * C + c];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int yy = y * S - 1 + dy;
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y * S - 1 + dy;
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int xx = x * S - 1 + dx;
-                        if ((unsigned)yy < (unsigned)ih && (unsigned)xx < (unsigned)iw)
-                            acc[dy * 3 + dx] = fmaf(X[(((size_t)b * ih + yy) * iw + xx) * C + c], g, acc[dy * 3 + dx]);
-                    }
-                }
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = x * S - 1 + dx;
+                if ((unsigned)yy < (unsigned)ih && (unsigned)xx < (unsigned)iw)
+                    acc[dy * 3 + dx] = fmaf(X[(((size_t)b * ih + yy) * iw + xx) * C + c], g, acc[dy * 3 + dx]);
             }
+        }
+    }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) part[((size_t)blockIdx.x * 9 + t) * C + c] = acc[t];
+    for (int t = 0; t < 9; ++t) sred[t * 256 + tid] = acc[t];
+    __syncthreads();
+    if (rsub == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float v = acc[t];
+            for (int k = 1; k < nsub; ++k) v += sred[t * 256 + tid + k * lanes_per_row];
+            part[((size_t)blockIdx.x * 9 + t) * C + c] = v;
         }
     }
 }
@@ -301,16 +309,27 @@ __global__ __launch_bounds__(256) void k_tr_colstats(const float* __restrict__ Z
     }
 }
 
-// sums[0][c], sums[1][c] -> stats[c] = (mean, 1/sqrt(var + eps)); moving statistics updated in place
-__global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict__ sums, int C, float n_rows_arg,
+// BatchNorm statistics from the per-workgroup partial sums part[p][0/1][c] (16 lanes per channel add the partial
+// rows in a fixed order -- the reduction and the finalisation in one launch): stats[c] = (mean, 1/sqrt(var + eps))
+// with the biased batch variance; moving statistics updated in place as Keras does
+__global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict__ part, int nparts, int C, float n_rows_arg,
                                                         const float* __restrict__ n_rows_dev, float momentum,
                                                         int unbiased_moving, float* __restrict__ stats,
                                                         float* __restrict__ moving_mean, float* __restrict__ moving_var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    const int l = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C)
+        for (int p = l; p < nparts; p += 16) {
+            s1 += part[((size_t)p * 2 + 0) * C + c];
+            s2 += part[((size_t)p * 2 + 1) * C + c];
+        }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if (c >= C || l != 0) return;
     const float n_rows = fmaxf((n_rows_dev != nullptr) ? *n_rows_dev : n_rows_arg, 1.f);   // PFN: P * T, known on the device only
-    const float mean = sums[c] / n_rows;
-    float var = sums[C + c] / n_rows - mean * mean;
+    const float mean = s1 / n_rows;
+    float var = s2 / n_rows - mean * mean;
     var = fmaxf(var, 0.f);
     stats[2 * c] = mean;
     stats[2 * c + 1] = 1.0f / sqrtf(var + TR_EPS);
@@ -775,9 +794,9 @@ void bn_relu_forward(const TrainCtx& cx, const float* Z, long rows, int C, const
                      float* stats, float* sums, float* mmean, float* mvar, float momentum, float* A, int ld, int co_off,
                      RowMap rm) {
     PP_LAUNCH("k_tr_colstats", k_tr_colstats, dim3(TR_NPART), dim3(256), 0, cx.stream, Z, rows, C, cx.part);
-    col_reduce(cx, C, sums);
-    PP_LAUNCH("k_tr_bn_finalize", k_tr_bn_finalize, dim3((C + 255) / 256), dim3(256), 0, cx.stream, (const float*)sums, C,
-              (float)rows, (const float*)nullptr, momentum, 1, stats, mmean, mvar);
+    PP_LAUNCH("k_tr_bn_finalize", k_tr_bn_finalize, dim3((C + 15) / 16), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
+              C, (float)rows, (const float*)nullptr, momentum, 1, stats, mmean, mvar);
+    (void)sums;
     PP_LAUNCH("k_tr_bn_relu", k_tr_bn_relu, dim3(blocks_for(rows * (C / 4))), dim3(256), 0, cx.stream, Z, rows, C,
               (const float*)stats, gamma, beta, A, ld, co_off, rm);
 }
@@ -808,8 +827,7 @@ template <int CPL>
 void pfn_forward(const TrainCtx& cx, const PfnT& p, const Lookup& L) {
     PP_LAUNCH("k_tr_pfn_rows", k_tr_pfn_rows, dim3(1), dim3(64), 0, cx.stream, p.npillars, p.batch, p.T, cx.pfn_nrows);
     PP_LAUNCH("k_tr_pfn_lin", (k_tr_pfn_lin<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, cx.pfn_y, cx.part);
-    col_reduce(cx, p.C, cx.pfn_sums);
-    PP_LAUNCH("k_tr_bn_finalize", k_tr_bn_finalize, dim3((p.C + 255) / 256), dim3(256), 0, cx.stream, (const float*)cx.pfn_sums,
+    PP_LAUNCH("k_tr_bn_finalize", k_tr_bn_finalize, dim3((p.C + 15) / 16), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
               p.C, 0.f, (const float*)cx.pfn_nrows, 0.01f, 0, cx.pfn_stats, L.s("pfn/bn/moving_mean"), L.s("pfn/bn/moving_variance"));
     PP_LAUNCH("k_tr_pfn_max", (k_tr_pfn_max<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, (const float*)cx.pfn_y,
               (const float*)cx.pfn_stats, L.p("pfn/bn/gamma"), L.p("pfn/bn/beta"), cx.pfn_feat, cx.pfn_arg);
