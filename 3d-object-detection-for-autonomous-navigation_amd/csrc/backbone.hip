@@ -1856,6 +1856,9 @@ long long* g_stamps = nullptr;   // tuning aid: device buffer for in-kernel stam
 #ifndef PP_SEP128_WPB
 #define PP_SEP128_WPB 2
 #endif
+#ifndef PP_SEP64_WPB
+#define PP_SEP64_WPB 3
+#endif
 
 // which kernel runs layer L (shared by the launcher and the profiler tags)
 static bool use_ws(const LayerDesc& L) {
@@ -1903,7 +1906,7 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
         const int unt = sep_u_nt(L, batch);
         const bool bf = L.d_wt16 != nullptr && split_precision(0);
         int wps;   // workgroups per CU of the instantiation launch_layer picks (launch_u<NT, S, WPS, WPB>)
-        if (L.stride == 1) wps = bf ? (unt == 128 ? PP_SEP128_WPB : 3) : (unt == 128 ? 3 : 4);
+        if (L.stride == 1) wps = bf ? (unt == 128 ? PP_SEP128_WPB : (unt == 64 ? PP_SEP64_WPB : 3)) : (unt == 128 ? 3 : 4);
         else wps = bf ? (unt == 128 ? 2 : 3) : (unt == 128 ? 2 : (unt == 64 ? 3 : 4));
         snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d,%d,%d>", unt, L.stride, wps, bf ? 1 : 0, (bf && L.d_occ) ? 1 : 0);
     } else if (deconv_uniform(L, 0) && deconv_k4_runs(L, layer_rows(L, batch), 0)) {
@@ -1960,7 +1963,7 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
                 else launch_k4<2>(a, L.n_total, s);
             } else if (L.stride == 1) {
                 if (nt == 128) launch_u<128, 1, 3, PP_SEP128_WPB>(a, L.n_total, s);
-                else if (nt == 64) launch_u<64, 1, 4, 3>(a, L.n_total, s);
+                else if (nt == 64) launch_u<64, 1, 4, PP_SEP64_WPB>(a, L.n_total, s);
                 else launch_u<32, 1, 4, 3>(a, L.n_total, s);
             } else {
                 if (nt == 128) launch_u<128, 2, 2, 2>(a, L.n_total, s);
