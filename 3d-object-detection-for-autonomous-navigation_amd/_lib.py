@@ -162,6 +162,25 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process, whatever the import order.  libpp_hip.so needs `libamdhip64.so.7`; the torch
+    wheel bundles its own copy (same SONAME) that libtorch_hip.so asks for as plain `libamdhip64.so`.  torch imported
+    first: its copy is mapped, the SONAME matches, libpp_hip.so binds to it.  libpp_hip.so first: the loader knows the
+    system copy only as `libamdhip64.so.7`, a later `import torch` maps the bundled one beside it, and the runtime
+    that initialises second finds no device (hipErrorNoDevice: "no ROCm-capable device is detected").  Loading the
+    system library once under the plain name as well makes the later request resolve to the same mapping."""
+    try:
+        with open("/proc/self/maps") as f:
+            if any("libamdhip64" in line for line in f):
+                return
+    except OSError:
+        pass
+    try:
+        ctypes.CDLL("libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        pass            # not on the default search path: libpp_hip.so's own RUNPATH still finds its runtime
+
+
 def lib():
     """Loads libpp_hip.so (raises if absent -- the HIP path is the only path)."""
     global _lib
@@ -171,6 +190,7 @@ def lib():
         raise RuntimeError(
             f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.")
+    _one_hip_runtime()
     L = ctypes.CDLL(SO_PATH)
     vp, i32, i64, f32p = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
     L.pp_abi_version.restype = ctypes.c_int

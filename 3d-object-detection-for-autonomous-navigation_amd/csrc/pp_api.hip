@@ -55,7 +55,7 @@ struct pp_engine {
     bool up_pending = false;              // the next pp_detect_async must wait for ev_up
     hipEvent_t ev_read[2] = {nullptr, nullptr};   // recorded on the main stream behind the pass that read buffer i
     float* d_points = nullptr;
-    float* d_points_sorted = nullptr;   // pillar-sorted copy left by k_voxel_frame (what the PFN streams)
+    float* d_points_sorted = nullptr;   // pillar-sorted copy left by k_sort_points (what the PFN streams)
     int* d_offsets = nullptr;
     int* d_cell = nullptr;
     int* d_first = nullptr;
@@ -360,6 +360,7 @@ static int fetch_canvas(pp_engine* e, float* canvas, int batch) {
 }
 
 // ---- stage pipelines (all enqueue on e->stream) ----
+const unsigned* sorted_idx(pp_engine* e);
 int run_voxelize(pp_engine* e, int batch, int max_n) {
     const bool lds_first = voxel_first_in_lds(max_n, e->ncell, e->cfg.max_voxels);
     int* d_first = lds_first ? nullptr : e->d_first;
@@ -376,7 +377,12 @@ int run_voxelize(pp_engine* e, int batch, int max_n) {
         ProfScope ps(e, "k_voxel_frame");
         launch_voxel_frame(e->d_offsets, e->d_cell, d_first, e->d_cellmap, e->d_keyA, e->d_idxA, e->d_keyB,
                            e->d_idxB, e->d_pstart, e->d_pcell, e->d_npillars, e->d_nvalid, batch, max_n, e->ncell,
-                           e->cfg.max_voxels, e->d_points, e->d_points_sorted, e->F, e->stream);
+                           e->cfg.max_voxels, e->stream);
+    }
+    {
+        ProfScope ps(e, "k_sort_points");
+        launch_sort_points(e->d_points, e->d_offsets, sorted_idx(e), e->d_nvalid, batch, max_n, e->F,
+                           e->d_points_sorted, e->stream);
     }
     HIPCHK(e, hipGetLastError());
     return PP_OK;

@@ -97,8 +97,10 @@ int voxel_sort_passes(int max_voxels);
 bool voxel_first_in_lds(int max_n, int ncell, int max_voxels);   // pass first = NULL to both launchers below
 void launch_voxel_frame(const int* offsets, const int* cell, const int* first, int* cellmap, unsigned* keyA,
                         unsigned* idxA, unsigned* keyB, unsigned* idxB, int* pillar_start, int* pillar_cell,
-                        int* npillars, int* nvalid, int batch, int max_n, int ncell, int max_voxels, const float* pts,
-                        float* pts_sorted, int F, hipStream_t s);
+                        int* npillars, int* nvalid, int batch, int max_n, int ncell, int max_voxels, hipStream_t s);
+// pts_sorted[n0 + j] = pts[n0 + sorted_idx[n0 + j]], j < nvalid[frame]: the pillar-sorted copy the PFN streams
+void launch_sort_points(const float* pts, const int* offsets, const unsigned* sorted_idx, const int* nvalid, int batch,
+                        int max_n, int F, float* pts_sorted, hipStream_t s);
 // pts_sorted: the pillar-sorted copy k_voxel_frame leaves ([sum N][F], frame b's valid points at offsets[b]..)
 void launch_voxel_expand(const float* pts_sorted, const int* offsets, const unsigned* sorted_idx, const int* pillar_start,
                          const int* pillar_cell, const int* npillars, int frame, int F, int T, int max_voxels,

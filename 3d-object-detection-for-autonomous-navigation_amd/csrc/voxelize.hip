@@ -21,7 +21,9 @@
 //     C. stable LSD radix sort by pillar id (<= 8 bits per pass; per-wave digit
 //        histograms in LDS; in-wave rank by digit-bit ballots), so points end
 //        up grouped by pillar in arrival order: the CSR layout the PFN reads.
-//     D. pillar_start[] from the key boundaries.
+//     D. pillar_start[] from the key boundaries, sorted point indices.
+//   k_sort_points  one thread per surviving point: the pillar-sorted copy of the points (the CSR
+//                  payload the PFN streams).
 // The padded [P,T,F] tensor of the reference is NOT materialised on the fused
 // path; k_voxel_expand produces it for the compat / parity entry point.
 //
@@ -110,8 +112,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
     const int* __restrict__ offsets, const int* __restrict__ cell, const int* __restrict__ first,
     int* __restrict__ cellmap, unsigned* keyA, unsigned* idxA, unsigned* keyB, unsigned* idxB,
     int* __restrict__ pillar_start, int* __restrict__ pillar_cell, int* __restrict__ npillars,
-    int* __restrict__ nvalid_out, int ncell, int max_voxels, int npass, int bits_rt,
-    const float* __restrict__ pts, float* __restrict__ pts_sorted, int F) {
+    int* __restrict__ nvalid_out, int ncell, int max_voxels, int npass, int bits_rt) {
     const int bits = (BITS > 0) ? BITS : bits_rt;
     __shared__ int s_tot[VWAVES];
     __shared__ int s_carry;
@@ -145,9 +146,9 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
     int ib = 1;
     while ((1 << ib) < n) ++ib;                 // bits of a point index
 #ifdef PP_VOX_STAMPS   // diagnostic build: phase times of frame 0 (100 MHz ticks), printed by thread 0
-    long long vst[12];
+    long long vst[24];
     int vsn = 0;
-#define V_STAMP() { if (vsn < 12) vst[vsn++] = wall_clock64(); }
+#define V_STAMP() { if (vsn < 24) vst[vsn++] = wall_clock64(); }
 #else
 #define V_STAMP() {}
 #endif
@@ -156,8 +157,16 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
         const int ppt = (n + VT - 1) / VT;      // <= PPT
         const int i0 = tid * ppt;
         int c[PPT];
+        if (ppt == PPT && ((n0 | n) & 3) == 0 && i0 + PPT <= n) {   // full frame: 16-byte loads (wave-uniform but for the tail)
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) c[k] = (k < ppt && i0 + k < n) ? fcell[i0 + k] : -1;
+            for (int k = 0; k < PPT; k += 4) {
+                const int4 v = *reinterpret_cast<const int4*>(fcell + i0 + k);
+                c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) c[k] = (k < ppt && i0 + k < n) ? fcell[i0 + k] : -1;
+        }
         int f[PPT];
         if (first != nullptr) {
 #pragma unroll
@@ -244,6 +253,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
                 ev[t] = (j < wend) ? sk[j] : 0u;
             }
             __syncthreads();
+            V_STAMP()   // pass: elements read, histogram cleared
             int rank[PPT];
 #pragma unroll
             for (int t = 0; t < PPT; ++t) {
@@ -274,6 +284,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
                 }
             }
             __syncthreads();
+            V_STAMP()   // pass: in-wave ranks + digit counts
             {
                 const int E = NB * VWAVES;
                 const int per = (E + VT - 1) / VT;
@@ -293,6 +304,7 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
                     }
             }
             __syncthreads();
+            V_STAMP()   // pass: block scan of the counts
 #pragma unroll
             for (int t = 0; t < PPT; ++t) {
                 if (wbeg + t * 64 + lane < wend) {
@@ -304,47 +316,21 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
             V_STAMP()   // 4, 5: sort passes
         }
         // sorted point indices + CSR row starts
-        unsigned* fin = ((npass & 1) ? idxB : idxA) + n0;     // the buffer the host reads (voxel_sort_passes)
         int* ps = pillar_start + (size_t)b * (max_voxels + 1);
         const unsigned imask = (1u << ib) - 1u;
-        // pillar-sorted copy of the points (the CSR payload the PFN streams with contiguous loads): one gather
-        // per point here, inside the one workgroup -- one XCD's L2 -- that owns the frame, instead of one per
-        // point in every PFN wave that touches the line
-        const float* fpts = pts + (size_t)n0 * F;
-        float* fsorted = pts_sorted + (size_t)n0 * F;
-        // (PPT elements per thread, all gathers of a thread issued before the first store: one memory round trip)
-        unsigned srcs[PPT];
+        // (the pillar-sorted copy of the points -- the CSR payload the PFN streams with contiguous loads -- is
+        // gathered by k_sort_points, next in the stream, on the whole chip: inside this one workgroup the 16 K
+        // gathers of a frame are bound by a single CU's address path, 15 us of the frame's 60)
+        unsigned* fin = ((npass & 1) ? idxB : idxA) + n0;     // sorted point indices (voxel_sort_passes)
 #pragma unroll
         for (int t = 0; t < PPT; ++t) {
             const int j = tid + t * VT;
-            srcs[t] = 0u;
             if (j < nv) {
                 const unsigned v = sk[j];
-                srcs[t] = v & imask;
-                fin[j] = srcs[t];
+                fin[j] = v & imask;
                 const unsigned k = v >> ib;
                 if (j == 0 || (sk[j - 1] >> ib) != k) ps[k] = j;
             }
-        }
-        if (F == 4) {
-            float4 pv[PPT];
-#pragma unroll
-            for (int t = 0; t < PPT; ++t) if (tid + t * VT < nv) pv[t] = reinterpret_cast<const float4*>(fpts)[srcs[t]];
-#pragma unroll
-            for (int t = 0; t < PPT; ++t) if (tid + t * VT < nv) reinterpret_cast<float4*>(fsorted)[tid + t * VT] = pv[t];
-        } else {
-            float px[PPT], py[PPT], pz[PPT];
-#pragma unroll
-            for (int t = 0; t < PPT; ++t)
-                if (tid + t * VT < nv) {
-                    px[t] = fpts[(size_t)srcs[t] * 3 + 0]; py[t] = fpts[(size_t)srcs[t] * 3 + 1]; pz[t] = fpts[(size_t)srcs[t] * 3 + 2];
-                }
-#pragma unroll
-            for (int t = 0; t < PPT; ++t)
-                if (tid + t * VT < nv) {
-                    const size_t j = (size_t)(tid + t * VT);
-                    fsorted[j * 3 + 0] = px[t]; fsorted[j * 3 + 1] = py[t]; fsorted[j * 3 + 2] = pz[t];
-                }
         }
         if (tid == 0) {
             ps[P] = nv;
@@ -487,25 +473,34 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
 
     // ---- D: CSR row starts from the key boundaries ----
     int* ps = pillar_start + (size_t)b * (max_voxels + 1);
-    {
-        const float* fpts = pts + (size_t)n0 * F;
-        float* fsorted = pts_sorted + (size_t)n0 * F;
-        for (int j = tid; j < nv; j += VT) {
-            const unsigned k = sk[j];
-            if (j == 0 || sk[j - 1] != k) ps[k] = j;
-            const unsigned src = sv[j];
-            if (F == 4) {
-                reinterpret_cast<float4*>(fsorted)[j] = reinterpret_cast<const float4*>(fpts)[src];
-            } else {
-                const float x = fpts[(size_t)src * 3 + 0], y = fpts[(size_t)src * 3 + 1], z = fpts[(size_t)src * 3 + 2];
-                fsorted[(size_t)j * 3 + 0] = x; fsorted[(size_t)j * 3 + 1] = y; fsorted[(size_t)j * 3 + 2] = z;
-            }
-        }
+    for (int j = tid; j < nv; j += VT) {
+        const unsigned k = sk[j];
+        if (j == 0 || sk[j - 1] != k) ps[k] = j;
     }
     if (tid == 0) {
         ps[P] = nv;
         npillars[b] = P;
         nvalid_out[b] = nv;
+    }
+}
+
+// pillar-sorted copy of the points: pts_sorted[n0 + j] = pts[n0 + idx[n0 + j]] for the nvalid[b] surviving points of
+// every frame (one thread per point, the whole chip; 16-byte accesses for F == 4, one 4-byte access per feature else)
+__global__ __launch_bounds__(256) void k_sort_points(const float* __restrict__ pts, const int* __restrict__ offsets,
+                                                     const unsigned* __restrict__ idx, const int* __restrict__ nvalid,
+                                                     int F, float* __restrict__ pts_sorted) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nvalid[b]) return;
+    const int n0 = offsets[b];
+    const unsigned src = idx[n0 + j];
+    const float* fp = pts + (size_t)(n0 + src) * F;
+    float* fs = pts_sorted + (size_t)(n0 + j) * F;
+    if (F == 4) {
+        *reinterpret_cast<float4*>(fs) = *reinterpret_cast<const float4*>(fp);
+    } else {
+        const float x = fp[0], y = fp[1], z = fp[2];
+        fs[0] = x; fs[1] = y; fs[2] = z;
     }
 }
 
@@ -570,8 +565,7 @@ void launch_cell_first(const float* pts, const int* offsets, int batch, int max_
 
 void launch_voxel_frame(const int* offsets, const int* cell, const int* first, int* cellmap, unsigned* keyA,
                         unsigned* idxA, unsigned* keyB, unsigned* idxB, int* pillar_start, int* pillar_cell,
-                        int* npillars, int* nvalid, int batch, int max_n, int ncell, int max_voxels, const float* pts,
-                        float* pts_sorted, int F, hipStream_t s) {
+                        int* npillars, int* nvalid, int batch, int max_n, int ncell, int max_voxels, hipStream_t s) {
     if (batch <= 0) return;
     int kb = 1;
     while ((1 << kb) < max_voxels) ++kb;
@@ -581,14 +575,20 @@ void launch_voxel_frame(const int* offsets, const int* cell, const int* first, i
     const bool big = max_n > VL_CAP;
 #define VOX_LAUNCH(B_, P_)                                                                                            \
     PP_LAUNCH("k_voxel_frame", (k_voxel_frame<B_, P_>), dim3(batch), dim3(VT), 0, s, offsets, cell, first, cellmap, keyA, \
-              idxA, keyB, idxB, pillar_start, pillar_cell, npillars, nvalid, ncell, max_voxels, npass, bits, pts,      \
-              pts_sorted, F)
+              idxA, keyB, idxB, pillar_start, pillar_cell, npillars, nvalid, ncell, max_voxels, npass, bits)
     if (bits == 7) {   // 8193..16384 pillars (the shipped configuration): unrolled digit loops
         if (big) VOX_LAUNCH(7, 32); else VOX_LAUNCH(7, 16);
     } else {
         if (big) VOX_LAUNCH(0, 32); else VOX_LAUNCH(0, 16);
     }
 #undef VOX_LAUNCH
+}
+
+void launch_sort_points(const float* pts, const int* offsets, const unsigned* sorted_idx, const int* nvalid, int batch,
+                        int max_n, int F, float* pts_sorted, hipStream_t s) {
+    if (batch <= 0 || max_n <= 0) return;
+    PP_LAUNCH("k_sort_points", k_sort_points, dim3((max_n + 255) / 256, batch), dim3(256), 0, s, pts, offsets,
+              sorted_idx, nvalid, F, pts_sorted);
 }
 
 void launch_voxel_expand(const float* pts, const int* offsets, const unsigned* sorted_idx, const int* pillar_start,

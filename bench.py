@@ -473,10 +473,21 @@ def main():
         e.load_weights(weights)
         e.set_calib(np.stack([calib[0]] * B), np.stack([calib[1]] * B), B)
 
+    torch_sync = [True]
+
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        for e in engines:          # the streams the work is on (the later legs run after these are closed)
+            if e._h:
+                e.sync()
+        if torch_sync[0]:
+            try:
+                torch.cuda.synchronize()
+            except Exception:      # torch's bundled runtime found no device (seen on some boxes); N = 1 only
+                if dist is not None:
+                    raise
+                torch_sync[0] = False
 
     feeder = Feeder(engines, stagings)
     elapsed = timed_run(feeder, args.steps, args.warmup, barrier)

@@ -260,29 +260,45 @@ def test_reloading_weights_does_not_leak(pp, hip_lib):
 
 
 def test_upload_from_device_memory_with_producer_stream(pp, hip_lib):
-    """pp_upload_points_device: the engine's stream waits for the producer's stream (a torch side stream that
-    is still writing the points when the call is made)."""
-    import torch
+    """pp_upload_points_device: the engine's stream waits for the producer's stream (a side stream of the HIP
+    runtime, still busy ahead of the copy that writes the points when the call is made)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")            # the process's one HIP runtime (pp_amd._lib._one_hip_runtime)
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+
+    def ok(rc):
+        assert rc == 0, f"hip error {rc}"
     B = 2
     eng = pp.Engine(pp.config.pedestrian_d435i_config(B), max_batch=B, max_points_per_frame=16384)
     eng.load_weights(pp.weights.init_weights(eng.d, seed=7))
     frames = [pp.synth.d435i_cloud(70 + i) for i in range(B)]
     want = [a.copy() for a in eng.detect(frames)]
-    pts = np.concatenate(frames, axis=0)
+    pts = np.ascontiguousarray(np.concatenate(frames, axis=0), np.float32)
     offs = np.array([0, frames[0].shape[0], pts.shape[0]], np.int32)
-    side = torch.cuda.Stream()
-    host = torch.from_numpy(pts).pin_memory()
-    big = torch.empty((4096, 4096), device="cuda")
-    with torch.cuda.stream(side):
-        for _ in range(20):                       # keep the producer stream busy ahead of the copy
-            big = big @ big * 1e-6
-        dev = host.to("cuda", non_blocking=True)
-    eng.upload_device(dev.data_ptr(), offs, producer_stream=side.cuda_stream)
+    side, dev, big = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    big_bytes = 1 << 30
+    ok(hip.hipStreamCreate(C.byref(side)))
+    ok(hip.hipMalloc(C.byref(dev), pts.nbytes))
+    ok(hip.hipMalloc(C.byref(big), big_bytes))
+    ok(hip.hipMemsetAsync(dev, 0xff, pts.nbytes, side))      # NaNs until the copy lands
+    for k in range(20):                                       # keep the producer stream busy ahead of the copy
+        ok(hip.hipMemsetAsync(big, k, big_bytes, side))
+    ok(hip.hipMemcpyAsync(dev, pts.ctypes.data_as(C.c_void_p), pts.nbytes, 1, side))
+    eng.upload_device(dev.value, offs, producer_stream=side.value)
     eng.detect_async()
     dets, n = eng.detections()
     assert np.array_equal(n, want[1]) and dets.tobytes() == want[0].tobytes()
-    torch.cuda.synchronize()
+    ok(hip.hipStreamSynchronize(side))
     eng.close()
+    ok(hip.hipFree(dev))
+    ok(hip.hipFree(big))
+    ok(hip.hipStreamDestroy(side))
 
 
 def test_stage_calls_invalidate_the_fused_state(pp, hip_lib):

@@ -206,3 +206,21 @@ def test_keras_checkpoint_name_mapping(pp):
     swapped["rpn"][k0] = swapped["rpn"][k0][..., :64]
     with pytest.raises(ValueError, match="shape"):
         pp.weights.from_keras_h5(swapped, d)
+
+
+@pytest.mark.parametrize("order", ["lib_first", "torch_first"])
+def test_one_hip_runtime_per_process(order):
+    """Whatever the import order of pp_amd's library and torch, the process maps ONE libamdhip64 (two copies: the
+    runtime that initialises second reports hipErrorNoDevice on the GPU box -- _lib._one_hip_runtime)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    first, second = ("import pp_amd; pp_amd._lib.lib()", "import torch") if order == "lib_first" else \
+                    ("import torch", "import pp_amd; pp_amd._lib.lib()")
+    code = (f"import sys; sys.path.insert(0, {root!r})\n{first}\n{second}\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "print('N', len(libs), libs)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("N ")][0]
+    assert line.split()[1] == "1", line
