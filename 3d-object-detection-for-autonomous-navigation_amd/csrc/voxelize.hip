@@ -254,35 +254,49 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
             }
             __syncthreads();
             V_STAMP()   // pass: elements read, histogram cleared
-            int rank[PPT];
+            // (the peer set of a lane is kept as two 32-bit words and narrowed by one xnor + and per word and digit
+            // bit: m = 0 / -1 from the lane's bit, peers &= ~(ballot ^ m); inactive lanes are outside the initial
+            // mask and stay outside.  Count reads and group-leader adds are relaxed workgroup-scope LDS operations
+            // (ds_read / ds_add in issue order); the counts read are consumed after the loop, so no step waits.)
+            int rank[PPT], rbase[PPT];
+            const unsigned lt_lo = (unsigned)lt, lt_hi = (unsigned)(lt >> 32);
 #pragma unroll
             for (int t = 0; t < PPT; ++t) {
                 rank[t] = 0;
+                rbase[t] = 0;
                 if (wbeg + t * 64 < wend) {                     // wave-uniform
                     const bool act = wbeg + t * 64 + lane < wend;
                     const unsigned d = (ev[t] >> shift) & dmask;
-                    unsigned long long peers = __ballot(act);
+                    const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
+                    unsigned plo = (unsigned)am, phi = (unsigned)(am >> 32);
                     if (BITS > 0) {
 #pragma unroll
                         for (int bit = 0; bit < BITS; ++bit) {
-                            const bool one = (d >> bit) & 1u;
-                            const unsigned long long bb = __ballot(act && one);
-                            peers &= one ? bb : ~bb;
+                            const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)d, bit, 1);      // 0 / -1
+                            const unsigned long long bb = __builtin_amdgcn_ballot_w64(__builtin_amdgcn_ubfe(d, bit, 1) != 0u);
+                            plo &= ~((unsigned)bb ^ m);
+                            phi &= ~((unsigned)(bb >> 32) ^ m);
                         }
                     } else {
                         for (int bit = 0; bit < bits; ++bit) {
-                            const bool one = (d >> bit) & 1u;
-                            const unsigned long long bb = __ballot(act && one);
-                            peers &= one ? bb : ~bb;
+                            const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)d, bit, 1);      // 0 / -1
+                            const unsigned long long bb = __builtin_amdgcn_ballot_w64(__builtin_amdgcn_ubfe(d, bit, 1) != 0u);
+                            plo &= ~((unsigned)bb ^ m);
+                            phi &= ~((unsigned)(bb >> 32) ^ m);
                         }
                     }
                     if (act) {
                         int* hp = &s_hist[wave * NB + d];   // [wave][digit]: the lanes of a wave spread over the banks
-                        rank[t] = *reinterpret_cast<volatile int*>(hp) + __popcll(peers & lt);
-                        if ((peers & lt) == 0ull) atomicAdd(hp, __popcll(peers));   // lowest lane of the group
+                        rbase[t] = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const unsigned blo = plo & lt_lo, bhi = phi & lt_hi;
+                        rank[t] = __popc(blo) + __popc(bhi);
+                        if ((blo | bhi) == 0u)                  // lowest lane of the group
+                            __hip_atomic_fetch_add(hp, __popc(plo) + __popc(phi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
+#pragma unroll
+            for (int t = 0; t < PPT; ++t) rank[t] += rbase[t];
             __syncthreads();
             V_STAMP()   // pass: in-wave ranks + digit counts
             {
