@@ -502,9 +502,13 @@ __global__ __launch_bounds__(VT) void k_voxel_frame(
 // every frame (one thread per point, the whole chip; 16-byte accesses for F == 4, one 4-byte access per feature else)
 __global__ __launch_bounds__(256) void k_sort_points(const float* __restrict__ pts, const int* __restrict__ offsets,
                                                      const unsigned* __restrict__ idx, const int* __restrict__ nvalid,
-                                                     int F, float* __restrict__ pts_sorted) {
-    const int b = blockIdx.y;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+                                                     int F, float* __restrict__ pts_sorted, int batch, int nchunk) {
+    // consecutive workgroup ids go to consecutive XCDs: all chunks of a frame on ONE XCD (frame = 8 * group + xcd), so a
+    // frame's 16-K random 12-byte reads hit lines that XCD's L2 already holds instead of fetching them once per XCD
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int chunk = r % nchunk, b = (r / nchunk) * 8 + xcd;
+    if (b >= batch) return;
+    const int j = chunk * 256 + threadIdx.x;
     if (j >= nvalid[b]) return;
     const int n0 = offsets[b];
     const unsigned src = idx[n0 + j];
@@ -601,8 +605,9 @@ void launch_voxel_frame(const int* offsets, const int* cell, const int* first, i
 void launch_sort_points(const float* pts, const int* offsets, const unsigned* sorted_idx, const int* nvalid, int batch,
                         int max_n, int F, float* pts_sorted, hipStream_t s) {
     if (batch <= 0 || max_n <= 0) return;
-    PP_LAUNCH("k_sort_points", k_sort_points, dim3((max_n + 255) / 256, batch), dim3(256), 0, s, pts, offsets,
-              sorted_idx, nvalid, F, pts_sorted);
+    const int nchunk = (max_n + 255) / 256;
+    PP_LAUNCH("k_sort_points", k_sort_points, dim3(8 * nchunk * ((batch + 7) / 8)), dim3(256), 0, s, pts, offsets,
+              sorted_idx, nvalid, F, pts_sorted, batch, nchunk);
 }
 
 void launch_voxel_expand(const float* pts, const int* offsets, const unsigned* sorted_idx, const int* pillar_start,
