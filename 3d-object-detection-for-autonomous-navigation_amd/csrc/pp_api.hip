@@ -899,7 +899,8 @@ int pp_finalize_weights(pp_handle e) {
         const char* env = getenv("PP_DENSE_CANVAS");
         const long long cells = (long long)e->ny * e->nx;
         LayerDesc& L0 = e->layers[0];
-        e->sparse_canvas = !(env && env[0] == '1') && cells >= 32768 && 4ll * e->cfg.max_voxels <= cells &&
+        const bool force = env && env[0] == '0';     // measurement switch: sparse wherever the kernels support it
+        e->sparse_canvas = !(env && env[0] == '1') && (force || (cells >= 32768 && 4ll * e->cfg.max_voxels <= cells)) &&
                            L0.in == e->d_canvas && sparse_input_supported(L0, e->B);
         L0.d_occ = e->sparse_canvas ? e->d_cellmap : nullptr;
         L0.occ_nz = e->nz;
