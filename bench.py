@@ -106,11 +106,12 @@ def stage_bytes(d, batch, n_points, n_pillars):
     F, C = d.num_point_features, d.pfn_filters
     return {
         "k_cell_first": batch * (4 * F * n_points + 4 * n_points),
-        "k_voxel_frame": batch * (4 * n_points * 2 + 16 * n_pillars + 4 * n_points),
+        "k_voxel_frame": batch * (4 * n_points * 2 + 16 * n_pillars),
         "k_pfn_canvas": batch * (4 * F * n_points + 16 * n_pillars + 4 * d.ny * d.nx * C),
         "k_occ_rowscan": batch * (4 * d.ny * d.nx * d.nz + 4 * d.ny * d.nx),
         "k_colscan": batch * (8 * d.ny * d.nx),
         "k_anchor_lookup": batch * (4 * d.ny * d.nx + d.num_anchors * 17),
+        "k_sort_points": batch * (4 * n_points + 2 * 4 * F * n_points),
         "k_postprocess": batch * (d.num_anchors * 5),
     }
 
