@@ -1060,11 +1060,21 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
 #ifdef PP_KERNEL_STAMPS
         if (ust && blockIdx.x < 64 && i + 1 < 64) a.stamps[4096 * 8 + blockIdx.x * 64 + i + 1] = wall_clock64();
 #endif
+#ifdef PP_KERNEL_STAMPS   // phase boundaries of ONE iteration (i == 4), shader clock: tools/phase_stamps.py
+#define U_PH(k) { if (ust && blockIdx.x < 64 && i == 4) a.stamps[4096 * 8 + blockIdx.x * 64 + 40 + (k)] = clock64(); }
+#else
+#define U_PH(k) {}
+#endif
+        U_PH(0)
         U_MFMA(0)
+        U_PH(1)
         U_STAGE(1)
+        U_PH(2)
         U_ISSUE()
+        U_PH(3)
         if (++mm_kc == nchunks) U_EPILOGUE()
         __syncthreads();
+        U_PH(4)
         U_MFMA(1)
         U_STAGE(0)
         U_ISSUE()
@@ -1082,6 +1092,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
 #undef U_MFMA
 #undef U_STAGE
 #undef U_ISSUE
+#undef U_PH
 #undef U_EPILOGUE
 #undef U_LOAD_CHUNK
 #undef U_TILE_OFFSETS
