@@ -7,8 +7,11 @@ keeps every 4th point starting at index 1, rotates camera axes into lidar axes a
     r2 = R.from_euler('x',  90, degrees=True).as_dcm()
     points = np.dot(np.dot(points, r), r2) + [0.0, 0.0, 1.0]
 
-`ros_numpy` / `rospy` are not available here, so this module starts from the [N,3] xyz array
-`pointcloud2_to_xyz_array` would return.  `realsense_to_lidar64` evaluates the reference's expression itself --
+`ros_numpy` / `rospy` are not available here: `pointcloud2_to_xyz` restates what
+`ros_numpy.point_cloud2.pointcloud2_to_xyz_array` does with a sensor_msgs/PointCloud2 (third-party dependency of the
+reference, not vendored: eric-wieser/ros_numpy, `point_cloud2.py` -- fields -> structured dtype with the message's
+offsets, one record per `point_step` bytes, rows of `row_step` bytes, NaN points dropped, x y z stacked) on the
+message's plain attributes, so the rest of this module starts from the [N,3] xyz array either way.  `realsense_to_lidar64` evaluates the reference's expression itself --
 same scipy matrices (their cos(90 deg) entries are 6.1e-17, not 0), same two float64 products, same addition --
 and is bit-identical to it.  `realsense_to_lidar` hands the engine float32 points (the voxeliser's input type):
 
@@ -21,6 +24,46 @@ and is bit-identical to it.  `realsense_to_lidar` hands the engine float32 point
 import numpy as np
 
 SENSOR_HEIGHT = 1.0
+
+# sensor_msgs/PointField datatype codes -> numpy (INT8 1 ... FLOAT64 8)
+_PF_TYPES = {1: "i1", 2: "u1", 3: "i2", 4: "u2", 5: "i4", 6: "u4", 7: "f4", 8: "f8"}
+
+
+def pointcloud2_to_xyz(data, width, height, point_step, row_step, fields, is_bigendian=False, remove_nans=True):
+    """sensor_msgs/PointCloud2 -> [N,3] array of its x y z fields (their own dtype, float32 for the d435i), what
+    `ros_numpy.point_cloud2.pointcloud2_to_xyz_array(msg)` returns (load_data.py:2433).
+
+    data: the message's byte buffer; fields: iterable of (name, offset, datatype, count) -- `(f.name, f.offset,
+    f.datatype, f.count)` of `msg.fields`.  Points with a non-finite coordinate are dropped (remove_nans), in
+    message order (row-major over height x width), as ros_numpy does."""
+    fl = sorted(((str(n), int(o), int(t), int(c)) for n, o, t, c in fields), key=lambda f: f[1])
+    names = {f[0] for f in fl}
+    if not {"x", "y", "z"} <= names:
+        raise ValueError(f"PointCloud2 without x/y/z fields: {sorted(names)}")
+    order = ">" if is_bigendian else "<"
+    spec = {"names": [], "formats": [], "offsets": [], "itemsize": int(point_step)}
+    for name, off, typ, cnt in fl:
+        if typ not in _PF_TYPES:
+            raise ValueError(f"PointField {name}: unknown datatype {typ}")
+        base = np.dtype(order + _PF_TYPES[typ])
+        if off + base.itemsize * max(cnt, 1) > point_step:
+            raise ValueError(f"PointField {name} (offset {off}) does not fit point_step {point_step}")
+        spec["names"].append(name)
+        spec["formats"].append(base if cnt <= 1 else (base, (cnt,)))
+        spec["offsets"].append(off)
+    dt = np.dtype(spec)
+    width, height, row_step = int(width), int(height), int(row_step)
+    if row_step < width * point_step:
+        raise ValueError(f"row_step {row_step} < width {width} x point_step {point_step}")
+    buf = np.frombuffer(data, dtype=np.uint8)
+    if buf.size < height * row_step:
+        raise ValueError(f"PointCloud2 data holds {buf.size} bytes, {height} rows of {row_step} needed")
+    rows = buf[:height * row_step].reshape(height, row_step)[:, :width * point_step]
+    rec = np.ascontiguousarray(rows).reshape(-1).view(dt)            # height * width records, row-major
+    xyz = np.stack([rec["x"], rec["y"], rec["z"]], axis=-1)
+    if remove_nans:
+        xyz = xyz[np.isfinite(xyz).all(axis=1)]
+    return xyz
 
 
 def _matrices():
