@@ -317,3 +317,40 @@ def test_stage_calls_invalidate_the_fused_state(pp, hip_lib):
     dets2, n2 = eng.detect(frames)                # a fresh upload restores it
     assert np.array_equal(n, n2) and dets.tobytes() == dets2.tobytes()
     eng.close()
+
+
+# ------------------------------------------------------------------ every voxeliser path, bit-exact
+@pytest.mark.parametrize("sizes", [(33000, 17, 40000, 0, 16384), (32768, 32769), (20000, 5000, 20001, 16385, 1, 9, 12345, 777, 3)])
+def test_voxeliser_paths_beyond_the_lds_capacity(pp, hip_lib, sizes):
+    """Frames of more than 32 768 points take k_voxel_frame's global-memory path (A-D over the key / index
+    buffers) and k_sort_points gathers from its index buffer; batches whose largest frame is <= 32 768 take the
+    32-points-per-thread LDS path for every frame (ragged sizes, offsets not multiples of 4, a batch that does not
+    fill a group of 8 XCDs).  Pillar order, coordinates, point counts AND the padded voxel contents against the C
+    oracle (the reference's sequential loop), with the `break` inside the large frames."""
+    rng = np.random.default_rng(sum(sizes))
+    B = len(sizes)
+    cfg = pp.config.pedestrian_d435i_config(B)
+    cfg["model"]["second"]["voxel_generator"].update(max_number_of_points_per_voxel=9, max_number_of_voxels=2500)
+    eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=max(max(sizes), 4096))
+    eng.load_weights(pp.weights.init_weights(eng.d, seed=7))
+    d = eng.d
+    frames = []
+    for n in sizes:
+        pts = np.stack([rng.uniform(-0.3, 6.8, n), rng.uniform(-2.8, 2.8, n), rng.uniform(-3.2, 3.2, n)], 1).astype(np.float32)
+        if n > 10:
+            pts[rng.integers(0, n, n // 7)] = pts[rng.integers(0, n, n // 7)]   # duplicates
+        frames.append(pts)
+    rect, trv, _ = pp.synth.default_calib()
+    eng.detect(frames, np.stack([rect] * B), np.stack([trv] * B))
+    im = eng.intermediates()
+    for b, pts in enumerate(frames):
+        ve, ce, ne = c_oracle.points_to_voxel(pts, d.voxel_size, d.pc_range, d.max_points, d.max_voxels)
+        P = ce.shape[0]
+        assert im["n_pillars"][b] == P, (sizes[b], im["n_pillars"][b], P)
+        assert np.array_equal(im["coors"][b, :P], ce), sizes[b]
+        assert np.array_equal(im["num_points"][b, :P], ne), sizes[b]
+    for b in np.argsort(sizes)[-2:]:                          # the padded tensor too (contents = the sorted copy)
+        v, c, k = eng.points_to_voxel(frames[b])
+        ve, ce, ne = c_oracle.points_to_voxel(frames[b], d.voxel_size, d.pc_range, d.max_points, d.max_voxels)
+        assert np.array_equal(c, ce) and np.array_equal(k, ne) and np.array_equal(v, ve), sizes[b]
+    eng.close()
