@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unordered_map>
 
 #include "pp_common.h"
 #include "train.h"
@@ -109,6 +110,12 @@ struct pp_engine {
     hipEvent_t off_ev[OFF_RING] = {nullptr, nullptr, nullptr, nullptr};
     int off_slot = 0;
     hipEvent_t ev_in = nullptr;   // orders the engine's stream behind a producer stream (pp_upload_points_device)
+    // zero-copy feed of small batches (pp_upload_points_async, batch <= PP_ZC_MAX_BATCH): one page-locked descriptor
+    // per input buffer, read by k_cell_first; no copy-engine transfer, no events
+    PpFeed* h_feed[2] = {nullptr, nullptr};
+    const PpFeed* d_feed[2] = {nullptr, nullptr};
+    bool zc = false;              // the uploaded batch is fed that way
+    std::unordered_map<const void*, const void*> host_dev;   // page-locked host address -> device address
 
     // training step (train.hip): shapes, flat layout and device buffers, set up by the first pp_train_* call
     struct TrainState {
@@ -119,7 +126,7 @@ struct pp_engine {
         bool buffers = false;
         // the ~250 launches of a step replay as one hipGraph while nothing they depend on changes
         hipGraphExec_t graph = nullptr;
-        int g_batch = -1, g_bucket = -1, g_buf = -1;
+        int g_batch = -1, g_bucket = -1, g_buf = -1, g_zc = 0;
         const void *g_params = nullptr, *g_grads = nullptr, *g_state = nullptr;
         pp_loss_config g_loss;
         int graph_state = 0;   // -1: capture failed once, plain launches from then on
@@ -128,7 +135,7 @@ struct pp_engine {
 
     int prof = 0;
     // pp_detect_async as one hipGraph launch (captured on first use per (batch, max points per frame))
-    struct GraphSlot { hipGraphExec_t exec = nullptr; int batch = -1, bucket = -1, buf = -1; unsigned long long used = 0; };
+    struct GraphSlot { hipGraphExec_t exec = nullptr; int batch = -1, bucket = -1, buf = -1, zc = 0; unsigned long long used = 0; };
     GraphSlot graphs[8];          // small LRU keyed by (batch, point-count bucket, input buffer)
     unsigned long long graph_tick = 0;
     int graph_state = 0;          // 0: try, -1: capture failed once (use plain launches)
@@ -371,7 +378,7 @@ int run_voxelize(pp_engine* e, int batch, int max_n) {
     {
         ProfScope ps(e, "k_cell_first");   // also clears the cell map
         launch_cell_first(e->d_points, e->d_offsets, batch, max_n, e->F, e->geom, e->d_cell, d_first, e->d_cellmap,
-                          e->stream);
+                          e->zc ? e->d_feed[e->in_buf] : nullptr, e->d_points, e->d_offsets, e->stream);
     }
     {
         ProfScope ps(e, "k_voxel_frame");
@@ -483,6 +490,7 @@ int set_offsets(pp_engine* e, const int32_t* off, int batch, hipStream_t stream)
         if (n > e->NMAX) return fail(e, PP_ERR_ARG, "frame %d has %d points > max_points_per_frame=%d", b, n, e->NMAX);
         if (n > max_n) max_n = n;
     }
+    e->zc = false;                                     // inputs arrive by copy: the first kernel reads device memory
     const int slot = e->off_slot;
     e->off_slot = (slot + 1) % pp_engine::OFF_RING;
     HIPCHK(e, hipEventSynchronize(e->off_ev[slot]));   // the copy that last used this slot has been consumed
@@ -708,6 +716,12 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             for (int i = 0; i < pp_engine::OFF_RING && st2 == PP_OK; ++i)
                 if (hipEventCreateWithFlags(&e->off_ev[i], hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
             if (st2 == PP_OK && hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
+            for (int i = 0; i < 2 && st2 == PP_OK; ++i) {
+                void* dp = nullptr;
+                if (hipHostMalloc((void**)&e->h_feed[i], sizeof(PpFeed) + (size_t)(e->B + 1) * sizeof(int)) != hipSuccess ||
+                    hipHostGetDevicePointer(&dp, e->h_feed[i], 0) != hipSuccess) st2 = PP_ERR_HIP;
+                e->d_feed[i] = (const PpFeed*)dp;
+            }
             if (st2 == PP_OK && hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
             for (int i = 0; i < 2 && st2 == PP_OK; ++i)
                 if (hipEventCreateWithFlags(&e->ev_read[i], hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
@@ -768,6 +782,7 @@ int pp_destroy(pp_handle e) {
     if (e->h_off_ring) (void)hipHostFree(e->h_off_ring);
     for (hipEvent_t ev : e->off_ev) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    for (PpFeed* f : e->h_feed) if (f) (void)hipHostFree(f);
     if (e->ev_up) (void)hipEventDestroy(e->ev_up);
     for (hipEvent_t ev : e->ev_read) if (ev) (void)hipEventDestroy(ev);
     if (e->d_voxels) (void)hipFree(e->d_voxels);
@@ -939,12 +954,70 @@ int pp_upload_points(pp_handle e, const float* points, const int32_t* frame_offs
     return PP_OK;
 }
 
+#ifndef PP_ZC_MAX_BATCH
+#define PP_ZC_MAX_BATCH 4
+#endif
+static bool zero_copy_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* s = getenv("PP_NO_ZERO_COPY"); v = (s && s[0] == '1') ? 0 : 1; }
+    return v != 0;
+}
+
+// Small batch, page-locked points: nothing is copied and no HIP call is made besides one event query -- the
+// descriptor of the other input buffer gets the points' device address and the offsets, and the next pass's first
+// kernel reads both over the host link (a 16 K-point frame is 196 KB: ~4 us of it) while it writes the device copies.
+static int feed_zero_copy(pp_engine* e, const float* points_pinned, const int32_t* off, int batch) {
+    if (!off) return fail(e, PP_ERR_ARG, "frame_offsets is NULL");
+    if (off[0] != 0) return fail(e, PP_ERR_ARG, "frame_offsets[0] must be 0");
+    int max_n = 0;
+    for (int b = 0; b < batch; ++b) {
+        const int n = off[b + 1] - off[b];
+        if (n < 0) return fail(e, PP_ERR_ARG, "frame_offsets not monotone at frame %d", b);
+        if (n > e->NMAX) return fail(e, PP_ERR_ARG, "frame %d has %d points > max_points_per_frame=%d", b, n, e->NMAX);
+        if (n > max_n) max_n = n;
+    }
+    const void* dev = nullptr;
+    if (off[batch] > 0) {
+        auto it = e->host_dev.find(points_pinned);
+        if (it != e->host_dev.end()) dev = it->second;
+        else {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, (void*)points_pinned, 0) != hipSuccess || dp == nullptr) {
+                (void)hipGetLastError();
+                return PP_ERR_UNSUPPORTED;
+            }
+            if (e->host_dev.size() > 256) e->host_dev.clear();
+            e->host_dev[points_pinned] = dp;
+            dev = dp;
+        }
+    }
+    const int nb = e->in_buf ^ 1;
+    // the pass that last read this buffer's descriptor (two uploads ago) must be through
+    HIPCHK(e, hipEventSynchronize(e->ev_read[nb]));
+    PpFeed* f = e->h_feed[nb];
+    f->src = (const float*)dev;
+    memcpy(f->offsets, off, (size_t)(batch + 1) * sizeof(int));
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    e->in_buf = nb;
+    e->d_points = e->d_points_buf[nb];
+    e->d_offsets = e->d_offsets_buf[nb];
+    e->cur_batch = batch;
+    e->cur_max_n = max_n;
+    e->up_pending = false;
+    e->zc = true;
+    return PP_OK;
+}
+
 int pp_upload_points_async(pp_handle e, const float* points_pinned, const int32_t* frame_offsets, int32_t batch) {
     if (!e) return PP_ERR_ARG;
     (void)hipSetDevice(e->device);
     int st = check_batch(e, batch); if (st) return st;
     if (frame_offsets && batch >= 1 && frame_offsets[batch] > 0 && !points_pinned)
         return fail(e, PP_ERR_ARG, "pp_upload_points_async: points is NULL");
+    if (frame_offsets && batch >= 1 && batch <= PP_ZC_MAX_BATCH && zero_copy_enabled()) {
+        st = feed_zero_copy(e, points_pinned, frame_offsets, batch);
+        if (st != PP_ERR_UNSUPPORTED) return st;      // (not device-mapped memory: the copy below still works)
+    }
     // on the copy stream, into the input buffer the running pass is not reading: no wait here, and the DMA runs
     // beside this handle's own kernels; pp_detect_async orders itself behind ev_up
     st = set_offsets(e, frame_offsets, batch, e->copy_stream); if (st) return st;
@@ -1068,7 +1141,7 @@ int pp_detect_async(pp_handle e) {
         pp_engine::GraphSlot* slot = nullptr;
         pp_engine::GraphSlot* lru = &e->graphs[0];
         for (auto& g : e->graphs) {
-            if (g.exec && g.batch == B && g.bucket == bucket && g.buf == e->in_buf) slot = &g;
+            if (g.exec && g.batch == B && g.bucket == bucket && g.buf == e->in_buf && g.zc == (e->zc ? 1 : 0)) slot = &g;
             if (g.used < lru->used) lru = &g;
         }
         if (slot == nullptr) {
@@ -1087,6 +1160,7 @@ int pp_detect_async(pp_handle e) {
                 slot->batch = B;
                 slot->bucket = bucket;
                 slot->buf = e->in_buf;
+                slot->zc = e->zc ? 1 : 0;
             } else {
                 slot->exec = nullptr;
                 e->graph_state = -1;           // fall back to plain launches for the life of the handle
@@ -1643,7 +1717,7 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
     bool launched = false;
     if (e->prof <= 0 && t->graph_state == 0 && graphs_enabled()) {
         const int bucket = graph_bucket(e, e->cur_max_n);
-        const bool hit = t->graph != nullptr && t->g_batch == batch && t->g_bucket == bucket && t->g_buf == e->in_buf &&
+        const bool hit = t->graph != nullptr && t->g_batch == batch && t->g_bucket == bucket && t->g_buf == e->in_buf && t->g_zc == (e->zc ? 1 : 0) &&
                          t->g_params == params_dev && t->g_grads == grads_dev && t->g_state == state_dev &&
                          memcmp(&t->g_loss, lc, sizeof(pp_loss_config)) == 0;
         if (!hit) {
@@ -1661,7 +1735,7 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
                 return fail(e, st, "pp_train_step: configuration not supported by the training kernels");
             }
             if (ok && st == PP_OK && g != nullptr && hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0) == hipSuccess) {
-                t->g_batch = batch; t->g_bucket = bucket; t->g_buf = e->in_buf;
+                t->g_batch = batch; t->g_bucket = bucket; t->g_buf = e->in_buf; t->g_zc = e->zc ? 1 : 0;
                 t->g_params = params_dev; t->g_grads = grads_dev; t->g_state = state_dev; t->g_loss = *lc;
             } else {
                 t->graph = nullptr;

@@ -90,8 +90,17 @@ struct LayerDesc {
 };
 
 // ----- launchers (each in its own .hip file) ----------------------------
+// small batches (the latency case) are fed without a copy engine: the first kernel reads the frames' offsets and
+// points straight from the caller's page-locked buffer (device-mapped) through this page-locked descriptor and
+// leaves the device copies the later kernels use (pts_dst / offsets_dst); feed == NULL: inputs are on the device
+struct PpFeed {
+    const float* src;        // device address of the caller's page-locked points [sum N, F]
+    int pad_[2];
+    int offsets[1];          // [batch + 1] follow
+};
 void launch_cell_first(const float* pts, const int* offsets, int batch, int max_n, int F, const VoxGeom& g,
-                       int* cell, int* first, int* cellmap, hipStream_t s);
+                       int* cell, int* first, int* cellmap, const PpFeed* feed, float* pts_dst, int* offsets_dst,
+                       hipStream_t s);
 // returns (through *sorted_in_b) nothing; the host derives the final buffer from voxel_sort_passes()
 int voxel_sort_passes(int max_voxels);
 bool voxel_first_in_lds(int max_n, int ncell, int max_voxels);   // pass first = NULL to both launchers below

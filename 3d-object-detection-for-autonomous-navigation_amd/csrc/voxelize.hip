@@ -44,17 +44,33 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 __global__ __launch_bounds__(256) void k_cell_first(const float* __restrict__ pts,
                                                     const int* __restrict__ offsets, int F, VoxGeom g,
                                                     int* __restrict__ cell, int* __restrict__ first,
-                                                    int* __restrict__ cellmap) {
+                                                    int* __restrict__ cellmap, const PpFeed* __restrict__ feed,
+                                                    float* __restrict__ pts_dst, int* __restrict__ offsets_dst) {
     const int b = blockIdx.y;
+    if (feed != nullptr) {   // zero-copy feed: host-resident offsets / points, device copies for the later kernels
+        offsets = feed->offsets;
+        pts = feed->src;
+    }
     // this frame's cell -> pillar map is cleared here (-1 = empty; k_voxel_frame, next in the stream, is the
     // first to write it): one launch less than a separate memset node
     if (cellmap != nullptr)
         for (int e = blockIdx.x * 256 + threadIdx.x; e < g.ncell; e += gridDim.x * 256) cellmap[(size_t)b * g.ncell + e] = -1;
     const int n0 = offsets[b];
-    const int n = offsets[b + 1] - n0;
+    const int n1 = offsets[b + 1];
+    const int n = n1 - n0;
+    if (feed != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        offsets_dst[b] = n0;
+        if (b == (int)gridDim.y - 1) offsets_dst[b + 1] = n1;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float* p = pts + (size_t)(n0 + i) * F;
+    const float* ps_ = pts + (size_t)(n0 + i) * F;
+    float p[3] = {ps_[0], ps_[1], ps_[2]};      // one trip over the host link per coordinate (zero-copy feed)
+    if (feed != nullptr) {
+        float* q = pts_dst + (size_t)(n0 + i) * F;
+        q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+        for (int j = 3; j < F; ++j) q[j] = ps_[j];
+    }
     int c3[3];
     bool ok = true;
 #pragma unroll
@@ -575,10 +591,12 @@ bool voxel_first_in_lds(int max_n, int ncell, int max_voxels) {
 }
 
 void launch_cell_first(const float* pts, const int* offsets, int batch, int max_n, int F, const VoxGeom& g,
-                       int* cell, int* first, int* cellmap, hipStream_t s) {
+                       int* cell, int* first, int* cellmap, const PpFeed* feed, float* pts_dst, int* offsets_dst,
+                       hipStream_t s) {
     if (batch <= 0) return;
     dim3 grid(max_n > 0 ? (max_n + 255) / 256 : 1, batch);   // at least one block per frame: it clears the cell map
-    PP_LAUNCH("k_cell_first", k_cell_first, grid, dim3(256), 0, s, pts, offsets, F, g, cell, first, cellmap);
+    PP_LAUNCH("k_cell_first", k_cell_first, grid, dim3(256), 0, s, pts, offsets, F, g, cell, first, cellmap, feed, pts_dst,
+              offsets_dst);
 }
 
 void launch_voxel_frame(const int* offsets, const int* cell, const int* first, int* cellmap, unsigned* keyA,

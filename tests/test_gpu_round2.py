@@ -354,3 +354,43 @@ def test_voxeliser_paths_beyond_the_lds_capacity(pp, hip_lib, sizes):
         ve, ce, ne = c_oracle.points_to_voxel(frames[b], d.voxel_size, d.pc_range, d.max_points, d.max_voxels)
         assert np.array_equal(c, ce) and np.array_equal(k, ne) and np.array_equal(v, ve), sizes[b]
     eng.close()
+
+
+@pytest.mark.parametrize("B", [1, 3, 4, 5])
+def test_zero_copy_feed_of_small_batches(pp, hip_lib, B):
+    """pp_upload_points_async with up to 4 frames feeds the first kernel straight from the page-locked buffer (no copy
+    engine, no events); 5 frames go through the copy stream.  Same detections, bit for bit, as the synchronous
+    upload, over many steps with the staging buffers recycled and the batch shape changing in between."""
+    eng = pp.Engine(pp.config.pedestrian_d435i_config(B), max_batch=B, max_points_per_frame=16384)
+    eng.load_weights(pp.weights.init_weights(eng.d, seed=7))
+    rect, trv, _ = pp.synth.default_calib()
+    eng.set_calib(np.stack([rect] * B), np.stack([trv] * B), B)
+    sets = [[pp.synth.d435i_cloud(900 + 10 * k + i, 16384 - 211 * i - 17 * k) for i in range(B)] for k in range(5)]
+    def same(d, n, w):           # rows past a frame's count are not defined
+        return np.array_equal(n, w[1]) and all(d[b, :n[b]].tobytes() == w[0][b, :n[b]].tobytes() for b in range(len(n)))
+
+    want = []
+    for fr in sets:
+        d, n = eng.detect(fr, np.stack([rect] * B), np.stack([trv] * B))
+        want.append((d.copy(), n.copy()))
+    stg = [eng.staging(fr) for fr in sets]
+    for rep in range(3):
+        for k in range(5):
+            eng.upload_async(stg[k])
+            eng.detect_async()
+            d, n = eng.detections()
+            assert same(d, n, want[k]), (rep, k)
+        if B > 1:                                           # another batch shape in between (other graph, other key)
+            eng.detect(sets[0][:1], rect[None], trv[None])
+    # pipelined: upload k+1 while k runs
+    eng.upload_async(stg[0]); eng.detect_async()
+    for k in range(1, 5):
+        eng.upload_async(stg[k])
+        d, n = eng.detections()
+        assert same(d, n, want[k - 1])
+        eng.detect_async()
+    d, n = eng.detections()
+    assert same(d, n, want[4])
+    for s_ in stg:
+        s_.close()
+    eng.close()
