@@ -422,6 +422,8 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (detail.train, configs[4])")
     ap.add_argument("--latency-b1", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-latency-b1", action="store_true", help="skip the batch-1 latency leg")
+    ap.add_argument("--only", choices=["cfgk", "train"], default=None,
+                    help="run ONE secondary leg by itself and print its dict (profiling runs: one regime per trace)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -458,6 +460,14 @@ def main():
 
     import pp_amd as pp
     pp._lib.lib()  # fails loudly if the HIP library is missing
+    if args.only is not None:
+        def _sync():
+            torch.cuda.synchronize()
+        leg = cfgk_leg(pp, local_rank, steps=max(12, min(args.steps, 60))) if args.only == "cfgk" else \
+            train_leg(pp, local_rank, rank, n_gpus, dist, comm_dev, _sync, steps=max(20, min(args.steps, 100)))
+        if rank == 0:
+            print(json.dumps({"leg": args.only, **leg}))
+        return
     B, N = args.batch, args.points
     cfg = pp.config.pedestrian_d435i_config(B)
     engines = [pp.Engine(cfg, max_batch=B, max_points_per_frame=max(N, 4096), device=local_rank)
