@@ -1133,8 +1133,10 @@ static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
 // and the four partial accumulators are added through LDS in a fixed order (deterministic), wave n
 // finishing channel tile n (bias, ReLU, 16-byte stores).  The chain is a quarter as long.
 // Split-precision bf16 only; cin % 64 == 0.
-template <int NT, int S>
-__global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
+// NW: waves per workgroup = ways the K range is split (4, or 8 when even the 4-way kernel leaves the chip to less
+// than one workgroup per CU: the chain halves again, one workgroup per CU by LDS)
+template <int NT, int S, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_sep_k4(GemmArgs a) {
     constexpr int KCH = 16, LSTR = KCH + 4;
     constexpr int WW = S + 3, NLD = 3 * WW;
     constexpr int SAW = 32 * LSTR;              // one A buffer (floats)
@@ -1142,15 +1144,15 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
     constexpr int NTILES = NT / 32;
     constexpr int NBL = NT * 2 * PP_NPIECE / 64;            // 16-byte weight items per lane per chunk
     constexpr int WV = 2 * SAW + 2 * SB;        // floats per wave
-    static_assert(4 * NTILES * 16 * 64 <= 4 * WV, "reduction scratch overlays the staging tiles");
-    __shared__ __attribute__((aligned(16))) float smem[4 * WV + 9 * 256];
+    static_assert(NW * NTILES * 16 * 64 <= NW * WV, "reduction scratch overlays the staging tiles");
+    __shared__ __attribute__((aligned(16))) float smem[NW * WV + 9 * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* const sAw = smem + wave * WV;
     float* const sBw = sAw + 2 * SAW;
-    float* const sDW = smem + 4 * WV;
+    float* const sDW = smem + NW * WV;
     const int n0 = blockIdx.y * NT;
     const int cin = a.cin;
-    const int niter = cin / (KCH * 4);          // chunks per wave (>= 1, checked by the launcher)
+    const int niter = cin / (KCH * NW);          // chunks per wave (>= 1, checked by the launcher)
 
     const int c4 = lane & 3, q = lane >> 2;
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
@@ -1220,7 +1222,7 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
     K4_LOAD(wave)
     {   // depthwise taps -> LDS, after the first window loads are in flight (one prologue round trip, not two)
         const int ngrp = cin / 4;
-        for (int e = tid; e < 9 * ngrp; e += 256) {
+        for (int e = tid; e < 9 * ngrp; e += NW * 64) {
             const int t = e / ngrp, g4 = e - t * ngrp;
             reinterpret_cast<float4*>(sDW)[g4 * 9 + t] = reinterpret_cast<const float4*>(a.dw)[e];
         }
@@ -1234,7 +1236,7 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
     const float bias_w = (wave < NTILES) ? a.bias[n0 + wave * 32 + r32] : 0.f;
     __syncthreads();   // depthwise taps visible
     K4_STAGE(wave, 0)
-    if (niter > 1) K4_LOAD(wave + 4)
+    if (niter > 1) K4_LOAD(wave + NW)
     const float* const cA0 = sAw + r32 * LSTR + h * (KCH / 2);
     const float* const cB0 = sBw + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
 #pragma unroll 1
@@ -1256,13 +1258,13 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
             }
         }
         if (j + 1 < niter) {
-            K4_STAGE(wave + 4 * (j + 1), buf ^ 1)
-            if (j + 2 < niter) K4_LOAD(wave + 4 * (j + 2))
+            K4_STAGE(wave + NW * (j + 1), buf ^ 1)
+            if (j + 2 < niter) K4_LOAD(wave + NW * (j + 2))
         }
     }
 #undef K4_LOAD
 #undef K4_STAGE
-    // ---- add the four partial sums: [wave][channel tile][register group][lane][4] through LDS ----
+    // ---- add the NW partial sums: [wave][channel tile][register group][lane][4] through LDS ----
     __syncthreads();   // every wave is done with its staging tiles
 #pragma unroll
     for (int n = 0; n < NTILES; ++n)
@@ -1279,7 +1281,7 @@ __global__ __launch_bounds__(256, 2) void k_sep_k4(GemmArgs a) {
         for (int g = 0; g < 4; ++g) {
             float4 t = *reinterpret_cast<const float4*>(smem + (((0 * NTILES + wave) * 4 + g) * 64 + lane) * 4);
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < NW; ++w) {
                 const float4 u = *reinterpret_cast<const float4*>(smem + (((w * NTILES + wave) * 4 + g) * 64 + lane) * 4);
                 t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             }
@@ -1304,9 +1306,21 @@ static bool sep_k4_runs(const void* wt16, int cin, int n_total, long long M, int
     const int half_cus = (force > 0) ? 2 * force : (cin <= 64 ? 3 : (cin <= 128 ? 5 : 6));
     return 2 * ((M + 31) / 32 * (n_total / 64)) <= (long long)half_cus * g_num_cus;
 }
+// eight-way split: cin = 256 and at most one workgroup per CU (the latency case proper: a frame or two).  Measured
+// at B=1 (tools/latency_b1.py): block3.1-.5 8.1 -> 7.2 us; the 128-channel layers gain nothing (block2.x 5.8 -> 5.6,
+// block3.0 6.0 -> 7.0: one iteration per wave leaves nothing to pipeline) and keep four waves
+static bool sep_k8_runs(int cin, int n_total, long long M) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PP_SEP_K8"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0 && cin % 256 == 0 && (M + 31) / 32 * (n_total / 64) <= (long long)g_num_cus;
+}
 template <int S>
 static void launch_k4(const GemmArgs& a, int n_total, hipStream_t s) {
     dim3 grid((unsigned)((a.M + 31) / 32), n_total / 64);
+    if (sep_k8_runs(a.cin, n_total, a.M)) {
+        PP_LAUNCH("k_sep_k4", (k_sep_k4<64, S, 8>), grid, dim3(512), 0, s, a);
+        return;
+    }
     PP_LAUNCH("k_sep_k4", (k_sep_k4<64, S>), grid, dim3(256), 0, s, a);
 }
 
@@ -1911,7 +1925,8 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
     char buf[64];
     if (L.kind == LAYER_SEP && use_ws(L) && sep_uniform(0) && layer_rows(L, batch) < (1 << 24)) {
         if (sep_k4_runs(L.d_wt16, L.cin, L.n_total, layer_rows(L, batch), 0)) {
-            snprintf(buf, sizeof(buf), "k_sep_k4<64,%d>", L.stride);
+            if (sep_k8_runs(L.cin, L.n_total, layer_rows(L, batch))) snprintf(buf, sizeof(buf), "k_sep_k4<64,%d,8>", L.stride);
+            else snprintf(buf, sizeof(buf), "k_sep_k4<64,%d>", L.stride);
             return std::string(buf);
         }
         const int unt = sep_u_nt(L, batch);
