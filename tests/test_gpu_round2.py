@@ -394,3 +394,22 @@ def test_zero_copy_feed_of_small_batches(pp, hip_lib, B):
     for s_ in stg:
         s_.close()
     eng.close()
+
+
+def test_async_upload_of_pageable_memory_falls_back_to_the_copy(pp, hip_lib):
+    """pp_upload_points_async with ordinary (not page-locked) memory: the zero-copy feed cannot map it, the call
+    falls back to the copy path and the results are the same."""
+    import types
+    eng = pp.Engine(pp.config.pedestrian_d435i_config(1), max_batch=1, max_points_per_frame=16384)
+    eng.load_weights(pp.weights.init_weights(eng.d, seed=7))
+    fr = [pp.synth.d435i_cloud(77)]
+    d0, n0 = eng.detect(fr)
+    d0, n0 = d0.copy(), n0.copy()
+    fake = types.SimpleNamespace(points=np.ascontiguousarray(fr[0], np.float32),
+                                 offsets=np.array([0, fr[0].shape[0]], np.int32))
+    for _ in range(3):
+        eng.upload_async(fake)
+        eng.detect_async()
+        d, n = eng.detections()
+        assert np.array_equal(n, n0) and d[0, :n[0]].tobytes() == d0[0, :n0[0]].tobytes()
+    eng.close()
