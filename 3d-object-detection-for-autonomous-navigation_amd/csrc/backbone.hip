@@ -1124,6 +1124,237 @@ static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Separable stride-1 layer with 256 output channels, depthwise computed ONCE per pixel (two-piece builds).
+//
+// k_sep_u runs a 256-channel layer as two columns of 128-channel workgroups, each computing the depthwise of its
+// pixels again (window loads and FMAs twice per pixel).  Here one 8-wave workgroup owns 128 pixels x all 256
+// channels: wave (pg, grp) belongs to pixel group pg = wave & 3 (32 pixels) and channel half grp = wave >> 2.  A
+// stream position is a PAIR of K-chunks: wave (pg, grp) stages chunk 2p + grp of its pixel group (loads, depthwise,
+// A tile -- exactly k_sep_u's staging), both waves of a pixel group then multiply BOTH chunks' A tiles with their own
+// 128 output channels.  Per output: half the window loads and half the depthwise FMAs, the same MFMAs, half as many
+// iterations (each with twice the matrix work to overlap).  113 KB of LDS: one workgroup (two waves per SIMD) per CU,
+// the occupancy of the 200-register k_sep_u<128>.  Skeleton (persistent XCD-aware tile walk, load / stage / multiply
+// cursors, one barrier per position, transposing epilogue) as k_sep_u.  cin % 64 == 0.
+#if PP_SPLIT_MODE != 0
+template <int CO>   // output channels of the layer (256)
+__global__ __launch_bounds__(512, 1) void k_sep_p(GemmArgs a, int ntiles) {
+    constexpr int KCH = 16, LSTR = KCH + 4, WW = 4, NLD = 12;
+    constexpr int SAW = 32 * LSTR;                   // one A tile (floats)
+    constexpr int SB1 = PP_NPIECE * CO * 8;          // weights of one chunk: [pieces][CO][16 f16]
+    constexpr int NTILES = CO / 64;                  // channel tiles of a wave (half the channels)
+    constexpr int NB4 = (2 * CO * 2 * PP_NPIECE) / 512;   // 16-byte weight items per thread per position
+    __shared__ __attribute__((aligned(16))) float smem[16 * SAW + 4 * SB1 + 9 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pg = wave & 3, grp = wave >> 2;
+    float* const sA = smem;                          // [pg][chunk of the pair][buffer][SAW]
+    float* const sB = smem + 16 * SAW;               // [buffer][chunk of the pair][SB1]
+    float* const sDW = smem + 16 * SAW + 4 * SB1;
+
+    const int xcd = blockIdx.x & 7, gl = blockIdx.x >> 3, GL = gridDim.x >> 3;
+    const int tbase = (int)(((long long)xcd * ntiles) >> 3), tend = (int)(((long long)(xcd + 1) * ntiles) >> 3);
+    const int first = tbase + gl;
+    if (first >= tend) return;
+    const int ntl = (tend - first + GL - 1) / GL;
+    const int cin = a.cin;
+    const int npos = cin / (2 * KCH);                // positions (chunk pairs) per tile: even (cin % 64 == 0)
+    const int total = ntl * npos;
+
+    const int c4 = lane & 3, q = lane >> 2;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc((const void*)a.wt16);
+    const int hw = a.px_h * a.px_w;
+    const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)a.px_w;
+    const int rs4 = a.in_w * cin * 4, cin4 = cin * 4;
+    unsigned aoff[NLD];
+#define P_TILE_OFFSETS(TILE)                                                                             \
+    {                                                                                                    \
+        const int pix0_ = (TILE) * 128 + pg * 32 + 2 * q;                                                \
+        const bool pvalid_ = pix0_ < a.M;                                                                \
+        const int pc_ = pvalid_ ? pix0_ : 0;                                                             \
+        int b_, rem_, y_, x0_;                                                                           \
+        fast_divmod(pc_, hw, inv_hw, b_, rem_);                                                          \
+        fast_divmod(rem_, a.px_w, inv_w, y_, x0_);                                                       \
+        const unsigned cbase_ = (unsigned)(((b_ * a.in_h + y_) * a.in_w + x0_) * cin) * 4u + PP_ZPAD_FLOATS * 4u; \
+        bool rowok_[3], colok_[WW];                                                                      \
+        _Pragma("unroll") for (int dy_ = 0; dy_ < 3; ++dy_) rowok_[dy_] = pvalid_ & ((unsigned)(y_ - 1 + dy_) < (unsigned)a.in_h); \
+        _Pragma("unroll") for (int dx_ = 0; dx_ < WW; ++dx_) colok_[dx_] = (unsigned)(x0_ - 1 + dx_) < (unsigned)a.in_w; \
+        _Pragma("unroll") for (int e = 0; e < NLD; ++e) {                                                \
+            const int dy_ = e / WW, dx_ = e % WW;                                                        \
+            const bool ok_ = rowok_[dy_] & colok_[dx_];                                                  \
+            aoff[e] = (ok_ ? cbase_ + (unsigned)((dy_ - 1) * rs4) + (unsigned)((dx_ - 1) * cin4) : 0u) + (unsigned)(c4 * 16); \
+        }                                                                                                \
+    }
+    // weight items of a position: [chunk of the pair][piece][row][half]
+    unsigned boff[NB4];
+    int bdst[NB4];
+    const unsigned bstep = (unsigned)(PP_NPIECE * a.n_total * 32);       // bytes per K-chunk
+#pragma unroll
+    for (int r = 0; r < NB4; ++r) {
+        const int e_ = tid + 512 * r;
+        const int cc = e_ / (CO * 2 * PP_NPIECE), e2 = e_ % (CO * 2 * PP_NPIECE);
+        const int piece = e2 / (CO * 2), rem = e2 % (CO * 2), row = rem >> 1, half = rem & 1;
+        boff[r] = (unsigned)(((piece * a.n_total + row) * 16 + half * 8) * 2) + (unsigned)cc * bstep;
+        bdst[r] = cc * SB1 + piece * (CO * 8) + row * 8 + ((half ^ ((row >> 3) & 1)) * 4);
+    }
+    float4 rin[NLD];
+    float4 rb[NB4];
+#define P_LOAD(POS)                                                                                      \
+    {                                                                                                    \
+        const unsigned so_ = (unsigned)(2 * (POS) + grp) * (KCH * 4);                                    \
+        _Pragma("unroll") for (int e = 0; e < NLD; ++e) rin[e] = buf_load16(rs_in, aoff[e], so_);        \
+        const unsigned sb_ = (unsigned)(2 * (POS)) * bstep;                                              \
+        _Pragma("unroll") for (int r = 0; r < NB4; ++r) rb[r] = buf_load16(rs_wt, boff[r], sb_);         \
+    }
+    int ld_tile = first, ld_pos = 0;
+    int st_pos = 0;
+    int mm_tile = first, mm_pos = 0;
+    P_TILE_OFFSETS(ld_tile)
+    P_LOAD(0)
+    ld_pos = 1;
+    {
+        const int ngrp = cin / 4;
+        for (int e = tid; e < 9 * ngrp; e += 512) {
+            const int t = e / ngrp, g4 = e - t * ngrp;
+            reinterpret_cast<float4*>(sDW)[g4 * 9 + t] = reinterpret_cast<const float4*>(a.dw)[e];
+        }
+    }
+    f32x16 acc[NTILES];
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const int h = lane >> 5, r32 = lane & 31;
+    const int n0 = grp * (CO / 2);
+    float bias_r[NTILES];
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n) bias_r[n] = a.bias[n0 + n * 32 + r32];
+    __syncthreads();
+
+    const float* const cA0 = sA + pg * (4 * SAW) + r32 * LSTR + h * (KCH / 2);
+    const float* const cB0 = sB + (n0 + r32) * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+#define P_MFMA(I)                                                                                        \
+    {                                                                                                    \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                  \
+            const float* cA = cA0 + (c * 2 + ((I) & 1)) * SAW;                                           \
+            const float* cB = cB0 + (((I) & 1) * 2 + c) * SB1;                                           \
+            const float4 a0 = *reinterpret_cast<const float4*>(cA), a1 = *reinterpret_cast<const float4*>(cA + 4);  \
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};                        \
+            bf16x8 ah, am, al;                                                                           \
+            split_bf16x3(av, ah, am, al);                                                                \
+            _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                         \
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(cB + n * 32 * 8);                     \
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(cB + CO * 8 + n * 32 * 8);           \
+                [[maybe_unused]] const bf16x8 bl = PC_LO(cB);                                            \
+                PC_PRODUCTS(acc[n], ah, am, al, bh, bm, bl)                                              \
+            }                                                                                            \
+        }                                                                                                \
+    }
+    // staging of position st_pos into buffer P & 1: this wave's chunk (2 st_pos + grp) of its pixel group, its
+    // share of the position's weights
+#define P_STAGE(P)                                                                                       \
+    {                                                                                                    \
+        constexpr int buf = (P) & 1;                                                                     \
+        const float* tw = sDW + ((2 * st_pos + grp) * 4 + c4) * 36;                                      \
+        float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;                                            \
+        _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                 \
+            _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                           \
+                const float4 w4 = *reinterpret_cast<const float4*>(tw + (dy * 3 + dx) * 4);              \
+                const float4 v0 = rin[dy * WW + dx], v1 = rin[dy * WW + 1 + dx];                         \
+                o0.x = fmaf(v0.x, w4.x, o0.x); o0.y = fmaf(v0.y, w4.y, o0.y);                            \
+                o0.z = fmaf(v0.z, w4.z, o0.z); o0.w = fmaf(v0.w, w4.w, o0.w);                            \
+                o1.x = fmaf(v1.x, w4.x, o1.x); o1.y = fmaf(v1.y, w4.y, o1.y);                            \
+                o1.z = fmaf(v1.z, w4.z, o1.z); o1.w = fmaf(v1.w, w4.w, o1.w);                            \
+            }                                                                                            \
+        float* dA = sA + pg * (4 * SAW) + (grp * 2 + buf) * SAW + (2 * q) * LSTR + c4 * 4;               \
+        *reinterpret_cast<float4*>(dA) = o0;                                                             \
+        *reinterpret_cast<float4*>(dA + LSTR) = o1;                                                      \
+        _Pragma("unroll") for (int r = 0; r < NB4; ++r)                                                  \
+            *reinterpret_cast<float4*>(sB + buf * (2 * SB1) + bdst[r]) = rb[r];                          \
+        if (++st_pos == npos) st_pos = 0;                                                                \
+    }
+#define P_ISSUE()                                                                                        \
+    {                                                                                                    \
+        if (ld_pos == 0) P_TILE_OFFSETS(ld_tile)                                                         \
+        P_LOAD(ld_pos)                                                                                   \
+        if (++ld_pos == npos) { ld_pos = 0; ld_tile += GL; }                                             \
+    }
+#define P_EPILOGUE()                                                                                     \
+    {                                                                                                    \
+        const int pw = mm_tile * 128 + pg * 32;                                                          \
+        if (pw < a.M) {                                                                                  \
+            const int qi = lane & 3, qj = r32 >> 2;                                                      \
+            float* dst = a.out + (size_t)(pw + 4 * h + qi) * a.ld_out + a.co_off + n0 + qj * 4;          \
+            const int ldo = a.ld_out;                                                                    \
+            _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                         \
+                const float bvn = bias_r[n];                                                             \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                          \
+                    float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);  \
+                    float x2 = fmaxf(acc[n][4 * g + 2] + bvn, 0.f), x3 = fmaxf(acc[n][4 * g + 3] + bvn, 0.f);  \
+                    quad_transpose4(x0, x1, x2, x3, lane);                                               \
+                    if (pw + 8 * g + 4 * h + qi < a.M)                                                   \
+                        *reinterpret_cast<float4*>(dst + (8 * g) * ldo + n * 32) = make_float4(x0, x1, x2, x3);  \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
+        _Pragma("unroll") for (int n = 0; n < NTILES; ++n)                                               \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;                              \
+        mm_pos = 0;                                                                                      \
+        mm_tile += GL;                                                                                   \
+    }
+    P_STAGE(0)
+    P_ISSUE()
+    __syncthreads();
+    int i = 0;
+    for (; i + 3 < total; i += 2) {
+        P_MFMA(0)
+        P_STAGE(1)
+        P_ISSUE()
+        if (++mm_pos == npos) P_EPILOGUE()
+        __syncthreads();
+        P_MFMA(1)
+        P_STAGE(0)
+        P_ISSUE()
+        if (++mm_pos == npos) P_EPILOGUE()
+        __syncthreads();
+    }
+    P_MFMA(0)
+    P_STAGE(1)
+    if (++mm_pos == npos) P_EPILOGUE()
+    __syncthreads();
+    P_MFMA(1)
+    ++mm_pos;
+    P_EPILOGUE()
+#undef P_MFMA
+#undef P_STAGE
+#undef P_ISSUE
+#undef P_EPILOGUE
+#undef P_LOAD
+#undef P_TILE_OFFSETS
+}
+
+static void launch_p(const GemmArgs& a, hipStream_t s) {
+    const int ntiles = (a.M + 127) / 128;
+    int gx = ntiles < g_num_cus ? ntiles : g_num_cus;
+    gx = (gx + 7) & ~7;
+    PP_LAUNCH("k_sep_p", k_sep_p<256>, dim3((unsigned)gx), dim3(512), 0, s, a, ntiles);
+}
+#endif   // PP_SPLIT_MODE != 0
+
+// does k_sep_p run this separable layer?  (256 output channels, stride 1, dense input, two-piece builds, large enough
+// for the persistent kernels; PP_SEP_P=0: never)
+static bool sep_p_runs(const void* wt16, int stride, int cin, int cout, int n_total, long long M, const int* occ, int dbg) {
+#if PP_SPLIT_MODE != 0
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PP_SEP_P"); v = (e && e[0] == '0') ? 0 : 1; }
+    // (the 128-channel instantiation, where k_sep_u already computes the depthwise once, measured 32 us against 28.5)
+    return v != 0 && wt16 != nullptr && split_precision(dbg) && stride == 1 && occ == nullptr && cout == 256 &&
+           n_total == 256 && cin % 64 == 0 && cin <= 256 && M < (1 << 24);
+#else
+    return false;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
 // Split-K separable layer for small maps (few frames in flight: the latency case).
 //
 // With a handful of 32-pixel wave tiles the chip is empty and a layer's time is the length of ONE
@@ -1929,6 +2160,7 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
             else snprintf(buf, sizeof(buf), "k_sep_k4<64,%d>", L.stride);
             return std::string(buf);
         }
+        if (sep_p_runs(L.d_wt16, L.stride, L.cin, L.cout, L.n_total, layer_rows(L, batch), L.d_occ, 0)) return std::string("k_sep_p");
         const int unt = sep_u_nt(L, batch);
         const bool bf = L.d_wt16 != nullptr && split_precision(0);
         int wps;   // workgroups per CU of the instantiation launch_layer picks (launch_u<NT, S, WPS, WPB>)
@@ -1984,6 +2216,12 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
             return PP_ERR_UNSUPPORTED;
         if (use_ws(L) && sep_uniform(ablate) && a.M < (1 << 24)) {   // k_sep_u's float-reciprocal index math
             const int nt = sep_u_nt(L, batch);
+#if PP_SPLIT_MODE != 0
+            if (!sep_k4_runs(a.wt16, a.cin, L.n_total, a.M, ablate) &&
+                sep_p_runs(a.wt16, L.stride, a.cin, L.cout, L.n_total, a.M, a.occ, ablate)) {   // depthwise once for 256 channels
+                launch_p(a, s);
+            } else
+#endif
             if (!(ablate & 16) && sep_k4_runs(a.wt16, a.cin, L.n_total, a.M, ablate)) {   // small map
                 if (L.stride == 1) launch_k4<1>(a, L.n_total, s);
                 else launch_k4<2>(a, L.n_total, s);

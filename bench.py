@@ -146,7 +146,7 @@ def cpu_baseline(pp, d, weights, frames, calib, budget_s=20.0):
 
 def is_split_kernel(sym):
     """Does this GEMM kernel run on the bf16 matrix pipe with split operands?  k_sep_u<NT,S,WPS,PREC,OCC>: PREC."""
-    if sym.startswith(("k_deconv_u", "k_deconv_k4", "k_sep_k4")):
+    if sym.startswith(("k_deconv_u", "k_deconv_k4", "k_sep_k4", "k_sep_p")):
         return True
     if sym.startswith("k_sep_u<"):
         params = sym[sym.index("<") + 1:sym.rindex(">")].split(",")
