@@ -413,3 +413,45 @@ def test_async_upload_of_pageable_memory_falls_back_to_the_copy(pp, hip_lib):
         d, n = eng.detections()
         assert np.array_equal(n, n0) and d[0, :n[0]].tobytes() == d0[0, :n0[0]].tobytes()
     eng.close()
+
+
+def test_depthwise_once_kernel_ragged_tiles(pp, hip_lib):
+    """k_sep_p (256-channel layers, 8-wave workgroups, chunk pairs) on a shape whose pixel count ends inside a
+    128-pixel tile: a 40x24 grid (block3 map 10x6 = 60 pixels per frame), 110 frames -> 6 600 pixels = 51.6 tiles.
+    Head maps of the big batch against the oracle for two frames, and against the same frames run alone (split-K
+    kernels) for three."""
+    import copy
+    B = 110
+    cfg = copy.deepcopy(pp.config.pedestrian_d435i_config(B))
+    cfg["eval_input_reader"]["feature_map_size"] = [1, 24, 40]
+    s = cfg["model"]["second"]
+    s["voxel_generator"].update(point_cloud_range=[0, -0.96, -3.0, 3.2, 0.96, 3.0], max_number_of_voxels=960)
+    s["target_assigner"]["anchor_generators"]["anchor_generator_stride"].update(offsets=[0.08, -0.96, -1.465])
+    big = pp.Engine(cfg, max_batch=B, max_points_per_frame=4096)
+    d = big.d
+    assert (d.nx, d.ny) == (40, 24)
+    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=13))
+    big.load_weights(w)
+    tags = big.layer_tags()
+    assert sum(t.startswith("k_sep_p:") for t in tags) == 5, tags
+    cfg1 = copy.deepcopy(cfg)
+    one = pp.Engine(cfg1, max_batch=1, max_points_per_frame=4096)
+    one.load_weights(w)
+    assert any(t.startswith("k_sep_k4") for t in one.layer_tags())
+    rng = np.random.default_rng(5)
+    frames = [rng.uniform([0, -0.96, -3], [3.2, 0.96, 3], (int(n), 3)).astype(np.float32)
+              for n in rng.integers(800, 3000, B)]
+    rect, trv, p2 = pp.synth.default_calib()
+    big.detect(frames, np.stack([rect] * B), np.stack([trv] * B))
+    imb = big.intermediates()
+    for i in (0, 57, 109):
+        one.detect([frames[i]], rect[None], trv[None])
+        im1 = one.intermediates()
+        for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+            np.testing.assert_allclose(im1[k][0], imb[k][i], rtol=2e-5, atol=2e-5)
+    for i in (3, 109):
+        ref = util_ref.oracle_detect(d, w, [frames[i]], rect, trv, p2)
+        for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+            np.testing.assert_allclose(imb[k][i], ref["preds"][k][0], rtol=TOL, atol=TOL)
+    big.close()
+    one.close()
