@@ -193,8 +193,11 @@ class Feeder:
             self._collect(k)
 
 
-def timed_run(feeder, steps, warmup, barrier):
-    for _ in range(warmup):
+SETTLE_STEPS = 40   # untimed set-up before the W warm-up steps: graph capture for both input buffers, clocks, caches
+
+
+def timed_run(feeder, steps, warmup, barrier, settle=0):
+    for _ in range(settle + warmup):
         feeder.step()
     feeder.drain()
     barrier()
@@ -501,7 +504,7 @@ def main():
                 torch_sync[0] = False
 
     feeder = Feeder(engines, stagings)
-    elapsed = timed_run(feeder, args.steps, args.warmup, barrier)
+    elapsed = timed_run(feeder, args.steps, args.warmup, barrier, settle=SETTLE_STEPS)
     elapsed = pp.frame_shard.max_over_ranks(elapsed, dist, comm_dev)
     counts = pp.frame_shard.gather_counts(B * args.steps, dist, comm_dev)
     ms_per_step = elapsed / args.steps * 1e3
