@@ -986,8 +986,12 @@ static int feed_zero_copy(pp_engine* e, const float* points_pinned, const int32_
                 (void)hipGetLastError();
                 return PP_ERR_UNSUPPORTED;
             }
-            if (e->host_dev.size() > 256) e->host_dev.clear();
-            e->host_dev[points_pinned] = dp;
+            // remembered only when the mapping is the identity (hipHostMalloc under unified addressing): a
+            // registered range may be unregistered and mapped elsewhere later
+            if (dp == (const void*)points_pinned) {
+                if (e->host_dev.size() > 256) e->host_dev.clear();
+                e->host_dev[points_pinned] = dp;
+            }
             dev = dp;
         }
     }
