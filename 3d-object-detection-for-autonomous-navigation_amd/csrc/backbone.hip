@@ -1806,6 +1806,252 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
 #undef D_FILL_OPIX
 }
 
+#if PP_SPLIT_MODE != 0
+// ---------------------------------------------------------------------------------------
+// Conv2DTranspose (kernel == stride) + BN + ReLU [+ fused SSD heads] with the INPUT operand resident in
+// registers (round 3).  k_deconv_u above gives every (pixel tile, tap) pair to a workgroup of its own tap
+// column: an input fragment is fetched (through L2) and split into its two float16 pieces once per tap -- 16
+// times for the 4x4 transposed convolution -- and the per-chunk split, address arithmetic and barrier share
+// the SIMD with the matrix work (measured: 54 of deconv3's 88 us remain with neither weights nor MFMAs).
+// Here the work is the flat list of (tile, tap) units, tile-major, cut into equal contiguous runs, one per
+// persistent workgroup (2 per CU): a wave loads the CIN channels of its 32 pixels ONCE per tile, splits them
+// once, and keeps the pieces in CIN/2 registers for all the taps of its run.  The K loop is then matrix
+// instructions and LDS fragment reads only:
+//   * weights stream through LDS as 16 KB panels = 8 steps of (32-channel n-tile, 16-channel K-chunk) x 2
+//     pieces, double-buffered, ONE workgroup barrier per panel (24 MFMAs per wave);
+//   * one 16-register accumulator (out^T of a 32-pixel x 32-channel tile, as k_deconv_u: lane = pixel) walks
+//     the tap's four n-tiles in turn; after an n-tile's last chunk: ReLU, optional concat-slice store, split,
+//     6 MFMAs of the fused head GEMM straight from the registers;
+//   * after the tap's last n-tile the lane's 4 x 16 bytes of its output pixel's head row are written (first
+//     branch: + head bias; later branches: + the partial sums fetched at the start of the unit).
+// cout == 128 (one tap = four n-tiles); CIN 64 / 128 / 256.  Same summation order per output as k_deconv_u
+// (chunks ascending, three products per chunk smallest first), so the two kernels agree bit for bit.
+#ifdef PP_DECONV_ABLATE   // tuning build: pp_bench_layer's ablation bits switch phases of k_deconv_r off (wrong results)
+#define R_ABL(BIT) (a.dbg & (BIT))
+#else
+#define R_ABL(BIT) false
+#endif
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void k_deconv_r(GemmArgs a, int nunits, int upw) {
+    constexpr int NCH = CIN / 16;                        // K-chunks
+    constexpr int STEPS = 4 * NCH;                       // (n-tile, chunk) steps of one unit
+    constexpr int NPU = STEPS / 8;                       // weight panels per unit (8 steps each): 8 / 4 / 2
+    constexpr int PANEL = 8 * 2 * 256;                   // floats: 8 steps x 2 pieces x 1 KB
+    constexpr int NB = 3;                                // LDS ring of weight panels
+    constexpr int PD = 2;                                // fragment reads run PD steps ahead of their products
+    constexpr int SHW = (128 / 16) * 2 * 32 * 8;         // head weights: [cout/16][2 pieces][32 cols][8 floats]
+    static_assert(PP_NPIECE == 2, "two-piece operands");
+    static_assert(STEPS % 4 == 0 && PD < 4, "fragment ring of four");
+    __shared__ __attribute__((aligned(16))) float sW[NB * PANEL];
+    __shared__ __attribute__((aligned(16))) float sHW[SHW];
+    __shared__ __attribute__((aligned(16))) float s_bias[128];
+    __shared__ float s_hbias[PP_HEAD_COLS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r32 = lane & 31;
+
+    // workgroup -> run of units; workgroups that share an XCD (equal blockIdx.x % 8) take neighbouring runs
+    int wg;
+    {
+        const int G = gridDim.x, q = G >> 3, r = G & 7, xcd = blockIdx.x & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int u0 = wg * upw, u1 = min(u0 + upw, nunits);
+    if (u0 >= u1) return;
+    const int ntaps = a.k * a.k;
+    const bool heads = a.head_mode != 0;
+    const int hwpx = a.px_h * a.px_w, OW = a.px_w * a.k;
+
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
+    const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt16);
+    // weight staging: item j of this thread = block (wave + 4j) of the panel = step (wave >> 1) + 2j, piece wave & 1;
+    // inside the 1 KB block: row lane >> 1, 16-byte half lane & 1 (halves swapped on odd groups of 8 rows)
+    const int srow = lane >> 1, shalf = lane & 1;
+    const unsigned wvoff = (unsigned)((((wave & 1) * a.n_total + srow) * 16 + shalf * 8) * 2);
+    const int wdst = wave * 256 + srow * 8 + ((shalf ^ ((srow >> 3) & 1)) * 4);
+    const unsigned cstep = (unsigned)(2 * a.n_total * 32);       // bytes per K-chunk of the split weights
+    float4 rw[4];
+    rw[0] = rw[1] = rw[2] = rw[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int tile = u0 / ntaps, tap = u0 - tile * ntaps;
+    // the flat sequence of weight panels of this run: (unit, panel) -> next to fetch
+    int ld_left = (u1 - u0) * NPU, ld_tap = tap, ld_p = 0;
+#define R_LOAD_NEXT()                                                                                    \
+    {                                                                                                    \
+        if (ld_left > 0 && !R_ABL(512)) {                                                                \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                           \
+                const int fs_ = ld_p * 8 + (wave >> 1) + 2 * j_;                                         \
+                const int nt_ = fs_ / NCH, c_ = fs_ % NCH;                                               \
+                rw[j_] = buf_load16(rs_wt, wvoff, (unsigned)c_ * cstep + (unsigned)((ld_tap * 128 + nt_ * 32) * 32)); \
+            }                                                                                            \
+        }                                                                                                \
+        --ld_left;                                                                                       \
+        if (++ld_p == NPU) { ld_p = 0; if (++ld_tap == ntaps) ld_tap = 0; }                              \
+    }
+#define R_STORE_W(SLOT)                                                                                  \
+    if (!R_ABL(512)) _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                    \
+        *reinterpret_cast<float4*>(sW + (SLOT) * PANEL + wdst + j_ * 1024) = rw[j_];
+
+    R_LOAD_NEXT()                        // panel 0
+    for (int e = tid; e < 128; e += 256) s_bias[e] = a.bias[e];
+    if (heads) {
+        for (int e = tid; e < SHW / 4; e += 256)
+            reinterpret_cast<float4*>(sHW)[e ^ ((e >> 4) & 1)] = reinterpret_cast<const float4*>(a.head_wt16)[e];
+        if (tid < PP_HEAD_COLS) s_hbias[tid] = a.head_bias[tid];
+    }
+    R_STORE_W(0)
+    R_LOAD_NEXT()                        // panel 1: written at step 0 of panel 0
+    __syncthreads();
+
+    bf16x8 xh[NCH], xm[NCH];             // the wave's 32 pixels x CIN channels, two float16 pieces
+    int tile_cur = -1, opix0 = 0;
+    bool ok = false;
+    const float* const cW = sW + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+    const float* const cHW = sHW + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
+    int slot = 0;                        // ring slot of the panel being multiplied
+    const float* pcur = cW;              // this lane's fragment base in that slot / in the next one
+    const float* pnxt = cW + PANEL;
+    // fragment ring: step fs uses entry fs % 4, requested PD steps earlier (also across panels and units)
+    bf16x8 fh[4], fm[4];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+        fh[i] = *reinterpret_cast<const bf16x8*>(pcur + i * 512);
+        fm[i] = *reinterpret_cast<const bf16x8*>(pcur + i * 512 + 256);
+    }
+
+    for (int u = u0; u < u1; ++u) {
+        if (tile != tile_cur) {          // uniform: fetch and split this tile's input once
+            tile_cur = tile;
+            const int pix = tile * 128 + wave * 32 + r32;
+            ok = pix < a.M;
+            const unsigned avo = (ok && !R_ABL(8)) ? (unsigned)(pix * CIN + h * 8) * 4u + PP_ZPAD_FLOATS * 4u : (unsigned)(h * 32);
+            float4 ra[NCH][2];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                ra[c][0] = buf_load16(rs_in, avo, (unsigned)c * 64u);
+                ra[c][1] = buf_load16(rs_in, avo + 16u, (unsigned)c * 64u);
+            }
+            const int pc = ok ? pix : 0;
+            const int pb = pc / hwpx, prem = pc - pb * hwpx;
+            const int py = prem / a.px_w, pxx = prem - py * a.px_w;
+            opix0 = (pb * a.px_h * a.k + py * a.k) * OW + pxx * a.k;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const float av[8] = {ra[c][0].x, ra[c][0].y, ra[c][0].z, ra[c][0].w, ra[c][1].x, ra[c][1].y, ra[c][1].z, ra[c][1].w};
+                bf16x8 lo_;
+                split_bf16x3(av, xh[c], xm[c], lo_);
+            }
+        }
+        const int ti = tap / a.k;
+        const size_t orow = (size_t)(opix0 + ti * OW + (tap - ti * a.k));      // this lane's output pixel
+        float* const hrow = a.head + orow * PP_HEAD_COLS + 4 * h;              // its columns 4h + {0..3, 8.., 16.., 24..}
+        f32x16 hacc;
+        if (a.head_mode == 2 && ok && !R_ABL(4)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(hrow + 8 * g);
+                hacc[4 * g] = t.x; hacc[4 * g + 1] = t.y; hacc[4 * g + 2] = t.z; hacc[4 * g + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hacc[r] = (a.head_mode == 1) ? s_hbias[DCH(r, h)] : 0.f;
+        }
+        float* const dst = (a.out != nullptr) ? a.out + orow * a.ld_out + a.co_off + 4 * h : nullptr;
+        f32x16 acc;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int fs = 0; fs < STEPS; ++fs) {
+            const int s = fs & 7, nt = fs / NCH, c = fs % NCH;       // compile-time after unrolling
+            if (c == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t = *reinterpret_cast<const float4*>(s_bias + nt * 32 + 8 * g + 4 * h);
+                    acc[4 * g] = t.x; acc[4 * g + 1] = t.y; acc[4 * g + 2] = t.z; acc[4 * g + 3] = t.w;
+                }
+            }
+            if (s == 4) {                // publishes the panel written at step 0 (read from step 8 - PD on)
+                if (!R_ABL(512)) __syncthreads();
+            }
+            {   // fragments of step fs + PD
+                const float* w_ = (s + PD < 8) ? pcur + (s + PD) * 512 : pnxt + (s + PD - 8) * 512;
+                fh[(fs + PD) & 3] = *reinterpret_cast<const bf16x8*>(w_);
+                fm[(fs + PD) & 3] = *reinterpret_cast<const bf16x8*>(w_ + 256);
+            }
+            if (!R_ABL(1)) { PC_PRODUCTS(acc, fh[fs & 3], fm[fs & 3], fm[fs & 3], xh[c], xm[c], xm[c]) }
+            if (s == 0) {                // the panel after this one -> its ring slot (fetched one panel ago)
+                const int ws = (slot + 1 == NB) ? 0 : slot + 1;
+                R_STORE_W(ws)
+            }
+            if (s == 1) { R_LOAD_NEXT() }    // and the one after that -> registers
+            if (s == 7) {
+                slot = (slot + 1 == NB) ? 0 : slot + 1;
+                pcur = pnxt;
+                pnxt = cW + ((slot + 1 == NB) ? 0 : slot + 1) * PANEL;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == NCH - 1) {          // n-tile nt complete: ReLU [+ concat slice] [+ its share of the head GEMM]
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r], 0.f);
+                if (heads && !R_ABL(2)) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const float av[8] = {v[8 * g], v[8 * g + 1], v[8 * g + 2], v[8 * g + 3],
+                                             v[8 * g + 4], v[8 * g + 5], v[8 * g + 6], v[8 * g + 7]};
+                        bf16x8 yh, ym, yl;
+                        split_bf16x3(av, yh, ym, yl);
+                        const float* hW = cHW + (nt * 2 + g) * 2 * 32 * 8;
+                        const bf16x8 gh = *reinterpret_cast<const bf16x8*>(hW);
+                        const bf16x8 gm = *reinterpret_cast<const bf16x8*>(hW + 32 * 8);
+                        PC_PRODUCTS(hacc, gh, gm, gm, yh, ym, yl)
+                    }
+                }
+                if (dst != nullptr && ok) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(dst + nt * 32 + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (heads && ok && !R_ABL(4)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(hrow + 8 * g) = make_float4(hacc[4 * g], hacc[4 * g + 1], hacc[4 * g + 2], hacc[4 * g + 3]);
+            if (a.cls_plane != nullptr) {   // register r of this lane is head column 8*(r/4) + 4h + r%4
+                float* cp = a.cls_plane + orow * a.cls_ncol;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = 8 * (r >> 2) + 4 * h + (r & 3) - a.cls_col0;
+                    if ((unsigned)col < (unsigned)a.cls_ncol) cp[col] = hacc[r];
+                }
+            }
+        }
+        if (++tap == ntaps) { tap = 0; ++tile; }
+    }
+#undef R_STORE_W
+#undef R_LOAD_NEXT
+#undef R_ABL
+}
+
+// runs where k_deconv_u would and the shape fits (cout == 128, cin 64 / 128 / 256); PP_DECONV_R=0 turns it off
+static bool deconv_r_runs(const LayerDesc& L, int ablate) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PP_DECONV_R"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || (ablate & 8192)) return false;
+    return L.cout == 128 && (L.cin == 64 || L.cin == 128 || L.cin == 256);
+}
+template <int CIN>
+static void launch_deconv_r(const GemmArgs& a, hipStream_t s) {
+    const int ntiles = (a.M + 127) / 128;
+    const long long U = (long long)ntiles * a.k * a.k;
+    const int slots = 2 * g_num_cus;
+    const int upw = (int)((U + slots - 1) / slots);                 // units per workgroup
+    const int G = (int)((U + upw - 1) / upw);
+    PP_LAUNCH("k_deconv_r", (k_deconv_r<CIN>), dim3((unsigned)G), dim3(256), 0, s, a, (int)U, upw);
+}
+#else
+static bool deconv_r_runs(const LayerDesc&, int) { return false; }
+#endif
+
 // ---------------------------------------------------------------------------------------
 // Split-K Conv2DTranspose (+ fused heads) for small maps: the four waves of a workgroup share one
 // 32-pixel x NT tile and take every fourth K-chunk each (private weight tiles, no barrier inside the K
@@ -2169,6 +2415,8 @@ std::string layer_kernel_name(const LayerDesc& L, int batch) {
         snprintf(buf, sizeof(buf), "k_sep_u<%d,%d,%d,%d,%d>", unt, L.stride, wps, bf ? 1 : 0, (bf && L.d_occ) ? 1 : 0);
     } else if (deconv_uniform(L, 0) && deconv_k4_runs(L, layer_rows(L, batch), 0)) {
         snprintf(buf, sizeof(buf), "k_deconv_k4<%d>", nt);
+    } else if (deconv_uniform(L, 0) && deconv_r_runs(L, 0)) {
+        snprintf(buf, sizeof(buf), "k_deconv_r<%d>", L.cin);
     } else if (deconv_uniform(L, 0)) {
         snprintf(buf, sizeof(buf), "k_deconv_u<%d,3>", nt);
     } else if (use_ws(L)) {
@@ -2257,6 +2505,12 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
             if (L.cout % 128 == 0) launch_deconv_k4<128>(a, L.n_total, s);
             else if (L.cout % 64 == 0) launch_deconv_k4<64>(a, L.n_total, s);
             else launch_deconv_k4<32>(a, L.n_total, s);
+#if PP_SPLIT_MODE != 0
+        } else if (deconv_uniform(L, ablate) && deconv_r_runs(L, ablate)) {   // input resident in registers
+            if (L.cin == 256) launch_deconv_r<256>(a, s);
+            else if (L.cin == 128) launch_deconv_r<128>(a, s);
+            else launch_deconv_r<64>(a, s);
+#endif
         } else if (deconv_uniform(L, ablate)) {
             if (L.cout % 128 == 0) launch_deconv_u<128>(a, L.n_total, s);
             else if (L.cout % 64 == 0) launch_deconv_u<64>(a, L.n_total, s);

@@ -115,7 +115,6 @@ struct pp_engine {
     PpFeed* h_feed[2] = {nullptr, nullptr};
     const PpFeed* d_feed[2] = {nullptr, nullptr};
     bool zc = false;              // the uploaded batch is fed that way
-    std::unordered_map<const void*, const void*> host_dev;   // page-locked host address -> device address
 
     // training step (train.hip): shapes, flat layout and device buffers, set up by the first pp_train_* call
     struct TrainState {
@@ -124,14 +123,20 @@ struct pp_engine {
         int64_t n_params = 0, n_state = 0;
         TrainCtx cx;
         bool buffers = false;
-        // the ~250 launches of a step replay as one hipGraph while nothing they depend on changes
-        hipGraphExec_t graph = nullptr;
-        int g_batch = -1, g_bucket = -1, g_buf = -1, g_zc = 0;
-        const void *g_params = nullptr, *g_grads = nullptr, *g_state = nullptr;
-        pp_loss_config g_loss;
+        // the ~250 launches of a step replay as one hipGraph while nothing they depend on changes; ONE GRAPH PER INPUT
+        // BUFFER: every upload flips the handle's input buffer (the kernels' point / offset pointers), so a single
+        // graph would be re-captured on every optimizer step
+        struct Graph {
+            hipGraphExec_t exec = nullptr;
+            int batch = -1, bucket = -1, zc = 0;
+            const void *params = nullptr, *grads = nullptr, *state = nullptr;
+            pp_loss_config loss;
+        } graph[2];
         int graph_state = 0;   // -1: capture failed once, plain launches from then on
+        int n_captures = 0, n_replays = 0;   // pp_train_graph_stats
     };
     TrainState* train = nullptr;
+    int f32_fallback_layers = 0;   // layers whose folded weights do not fit float16 pieces (pp_finalize_weights)
 
     int prof = 0;
     // pp_detect_async as one hipGraph launch (captured on first use per (batch, max points per frame))
@@ -346,6 +351,22 @@ std::vector<float> split_weights_bf16x3(const std::vector<float>& wt, int n_tota
     std::vector<float> packed(out.size() / 2);
     memcpy(packed.data(), out.data(), out.size() * 2);
     return packed;
+}
+
+// May these BN-folded weights go to the two-float16-piece operand layout?  A piece is a float16: |w| must stay below
+// its largest finite value (with headroom for the rounding of hi); a layer that fails runs on the float32 matrix
+// instruction instead (its d_wt16 stays NULL and the launchers pick the PREC = 0 instantiations).  Small weights need
+// no guard: below 2^-3 the mid piece is a float16 subnormal, so a weight carries an ABSOLUTE error of at most 2^-25,
+// which is what bounds the error of a dot product whose other terms are O(1).
+static bool f16_pair_range_ok(const std::vector<float>& wt) {
+#if PP_SPLIT_MODE == 0
+    (void)wt;
+    return true;          // bfloat16 pieces have float32's exponent range
+#else
+    for (float w : wt)
+        if (!(fabsf(w) < 32768.f)) return false;      // also catches NaN / inf
+    return true;
+#endif
 }
 
 // canvas -> host (debug taps).  With the sparse canvas the cells without a pillar were never written: they are
@@ -777,7 +798,7 @@ int pp_destroy(pp_handle e) {
     graph_invalidate(e);
     for (void* p : e->allocs) (void)hipFree(p);
     for (void* p : e->wallocs) (void)hipFree(p);
-    if (e->train && e->train->graph) (void)hipGraphExecDestroy(e->train->graph);
+    if (e->train) for (auto& tg : e->train->graph) if (tg.exec) (void)hipGraphExecDestroy(tg.exec);
     delete e->train;
     if (e->h_off_ring) (void)hipHostFree(e->h_off_ring);
     for (hipEvent_t ev : e->off_ev) if (ev) (void)hipEventDestroy(ev);
@@ -854,6 +875,7 @@ int pp_finalize_weights(pp_handle e) {
         }
     }
     int bi = 0, li = 0;
+    e->f32_fallback_layers = 0;
     for (LayerDesc& L : e->layers) {
         if (L.kind == LAYER_SEP) {
             const std::string pre = "rpn/block" + std::to_string(bi + 1) + "/" + std::to_string(li);
@@ -865,7 +887,9 @@ int pp_finalize_weights(pp_handle e) {
                 for (int co = 0; co < L.cout; ++co) wt[(size_t)co * L.cin + ci] = (*pw)[(size_t)ci * L.cout + co] * sc[co];
             int st = upload(e, &L.d_dw, *dw); if (st) return st;
             st = upload(e, &L.d_wt, wt); if (st) return st;
-            if (L.cin % 16 == 0) { st = upload(e, &L.d_wt16, split_weights_bf16x3(wt, L.n_total, L.cin)); if (st) return st; }
+            L.d_wt16 = nullptr;
+            if (L.cin % 16 == 0 && f16_pair_range_ok(wt)) { st = upload(e, &L.d_wt16, split_weights_bf16x3(wt, L.n_total, L.cin)); if (st) return st; }
+            else ++e->f32_fallback_layers;
             st = upload(e, &L.d_bias, sh); if (st) return st;
             ++li;
         } else if (L.kind == LAYER_DECONV) {
@@ -878,14 +902,17 @@ int pp_finalize_weights(pp_handle e) {
                 for (int ci = 0; ci < L.cin; ++ci) wt[n * L.cin + ci] = (*k)[n * L.cin + ci] * sc[co];
             }
             int st = upload(e, &L.d_wt, wt); if (st) return st;
-            if (L.cin % 16 == 0) { st = upload(e, &L.d_wt16, split_weights_bf16x3(wt, L.n_total, L.cin)); if (st) return st; }
+            L.d_wt16 = nullptr;
+            L.d_head_wt16 = nullptr;
+            if (L.cin % 16 == 0 && f16_pair_range_ok(wt)) { st = upload(e, &L.d_wt16, split_weights_bf16x3(wt, L.n_total, L.cin)); if (st) return st; }
+            else ++e->f32_fallback_layers;
             st = upload(e, &L.d_bias, sh); if (st) return st;
             if (L.head_mode != 0) {   // this branch's [PP_HEAD_COLS][cout] slice of the head matrix
                 std::vector<float> hw((size_t)PP_HEAD_COLS * L.cout);
                 for (int o = 0; o < PP_HEAD_COLS; ++o)
                     for (int c = 0; c < L.cout; ++c) hw[(size_t)o * L.cout + c] = headw[(size_t)o * e->CC + L.co_off + c];
                 st = upload(e, &L.d_head_wt, hw); if (st) return st;
-                if (L.cout % 32 == 0) {
+                if (L.cout % 32 == 0 && f16_pair_range_ok(hw)) {
                     // k_deconv_u feeds the head GEMM from its accumulator registers: slot (h, j) of 16-channel group
                     // (n, g) holds channel n*32 + (j&3) + 8*(2g + (j>>2)) + 4h (the 32x32 MFMA result layout); the
                     // head kernels get the same order of k
@@ -920,6 +947,7 @@ int pp_finalize_weights(pp_handle e) {
         L0.d_occ = e->sparse_canvas ? e->d_cellmap : nullptr;
         L0.occ_nz = e->nz;
     }
+    e->tag_batch = -1;            // which kernel runs a layer may depend on its weights (float16 range fallback)
     e->weights_ready = true;
     return PP_OK;
 }
@@ -957,6 +985,18 @@ int pp_upload_points(pp_handle e, const float* points, const int32_t* frame_offs
 #ifndef PP_ZC_MAX_BATCH
 #define PP_ZC_MAX_BATCH 4
 #endif
+// live pp_host_alloc blocks (base -> bytes) whose device mapping is the identity; pp_host_free removes its entry
+// BEFORE the memory goes back to the runtime, so a later lookup of a recycled address cannot hit
+static std::mutex g_pinned_mu;
+static std::map<uintptr_t, size_t> g_pinned;
+static bool pinned_block_holds(const void* p, size_t bytes) {
+    const uintptr_t a = (uintptr_t)p;
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    auto it = g_pinned.upper_bound(a);
+    if (it == g_pinned.begin()) return false;
+    --it;
+    return a >= it->first && a + bytes <= it->first + it->second;
+}
 static bool zero_copy_enabled() {
     static int v = -1;
     if (v < 0) { const char* s = getenv("PP_NO_ZERO_COPY"); v = (s && s[0] == '1') ? 0 : 1; }
@@ -978,19 +1018,18 @@ static int feed_zero_copy(pp_engine* e, const float* points_pinned, const int32_
     }
     const void* dev = nullptr;
     if (off[batch] > 0) {
-        auto it = e->host_dev.find(points_pinned);
-        if (it != e->host_dev.end()) dev = it->second;
+        // Device address of the caller's buffer.  No address is remembered per handle (a freed buffer's address can
+        // come back as pageable memory): a range inside a LIVE pp_host_alloc block is its own device address
+        // (hipHostMalloc under unified addressing) -- one lookup in the library's registry, which pp_host_free
+        // updates -- and anything else is asked of the runtime on every call (pageable memory fails there and the
+        // caller falls back to the copy path).
+        const size_t bytes = (size_t)off[batch] * e->F * sizeof(float);
+        if (pinned_block_holds(points_pinned, bytes)) dev = points_pinned;
         else {
             void* dp = nullptr;
             if (hipHostGetDevicePointer(&dp, (void*)points_pinned, 0) != hipSuccess || dp == nullptr) {
                 (void)hipGetLastError();
                 return PP_ERR_UNSUPPORTED;
-            }
-            // remembered only when the mapping is the identity (hipHostMalloc under unified addressing): a
-            // registered range may be unregistered and mapped elsewhere later
-            if (dp == (const void*)points_pinned) {
-                if (e->host_dev.size() > 256) e->host_dev.clear();
-                e->host_dev[points_pinned] = dp;
             }
             dev = dp;
         }
@@ -1039,10 +1078,21 @@ int pp_host_alloc(int64_t bytes, void** out) {
         (void)hipGetLastError();
         return fail(nullptr, PP_ERR_HIP, "pp_host_alloc: hipHostMalloc(%lld) failed", (long long)bytes);
     }
+    void* dp = nullptr;   // registered for the zero-copy feed only when the device sees the block at the same address
+    if (hipHostGetDevicePointer(&dp, *out, 0) == hipSuccess && dp == *out) {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        g_pinned[(uintptr_t)*out] = (size_t)(bytes ? bytes : 1);
+    } else {
+        (void)hipGetLastError();
+    }
     return PP_OK;
 }
 
 int pp_host_free(void* p) {
+    if (p) {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        g_pinned.erase((uintptr_t)p);
+    }
     if (p && hipHostFree(p) != hipSuccess) return fail(nullptr, PP_ERR_HIP, "pp_host_free: hipHostFree failed");
     return PP_OK;
 }
@@ -1721,14 +1771,15 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
     bool launched = false;
     if (e->prof <= 0 && t->graph_state == 0 && graphs_enabled()) {
         const int bucket = graph_bucket(e, e->cur_max_n);
-        const bool hit = t->graph != nullptr && t->g_batch == batch && t->g_bucket == bucket && t->g_buf == e->in_buf && t->g_zc == (e->zc ? 1 : 0) &&
-                         t->g_params == params_dev && t->g_grads == grads_dev && t->g_state == state_dev &&
-                         memcmp(&t->g_loss, lc, sizeof(pp_loss_config)) == 0;
+        pp_engine::TrainState::Graph& tg = t->graph[e->in_buf & 1];
+        const bool hit = tg.exec != nullptr && tg.batch == batch && tg.bucket == bucket && tg.zc == (e->zc ? 1 : 0) &&
+                         tg.params == params_dev && tg.grads == grads_dev && tg.state == state_dev &&
+                         memcmp(&tg.loss, lc, sizeof(pp_loss_config)) == 0;
         if (!hit) {
-            if (t->graph) {
+            if (tg.exec) {
                 HIPCHK(e, hipStreamSynchronize(e->stream));
-                (void)hipGraphExecDestroy(t->graph);
-                t->graph = nullptr;
+                (void)hipGraphExecDestroy(tg.exec);
+                tg.exec = nullptr;
             }
             hipGraph_t g = nullptr;
             bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -1738,18 +1789,20 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
                 if (g) (void)hipGraphDestroy(g);
                 return fail(e, st, "pp_train_step: configuration not supported by the training kernels");
             }
-            if (ok && st == PP_OK && g != nullptr && hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0) == hipSuccess) {
-                t->g_batch = batch; t->g_bucket = bucket; t->g_buf = e->in_buf; t->g_zc = e->zc ? 1 : 0;
-                t->g_params = params_dev; t->g_grads = grads_dev; t->g_state = state_dev; t->g_loss = *lc;
+            if (ok && st == PP_OK && g != nullptr && hipGraphInstantiate(&tg.exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                tg.batch = batch; tg.bucket = bucket; tg.zc = e->zc ? 1 : 0;
+                tg.params = params_dev; tg.grads = grads_dev; tg.state = state_dev; tg.loss = *lc;
+                ++t->n_captures;
             } else {
-                t->graph = nullptr;
+                tg.exec = nullptr;
                 t->graph_state = -1;
                 (void)hipGetLastError();
             }
             if (g) (void)hipGraphDestroy(g);
         }
-        if (t->graph != nullptr) {
-            HIPCHK(e, hipGraphLaunch(t->graph, e->stream));
+        if (tg.exec != nullptr) {
+            HIPCHK(e, hipGraphLaunch(tg.exec, e->stream));
+            ++t->n_replays;
             launched = true;
             st = PP_OK;
         }
@@ -1765,6 +1818,13 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->results_batch = 0;          // the head map now holds training-mode outputs, not detections
     e->cls_plane_live = false;
+    return PP_OK;
+}
+
+int pp_train_graph_stats(pp_handle e, int32_t* captures, int32_t* replays) {
+    if (!e) return PP_ERR_ARG;
+    if (captures) *captures = e->train ? e->train->n_captures : 0;
+    if (replays) *replays = e->train ? e->train->n_replays : 0;
     return PP_OK;
 }
 

@@ -4,7 +4,9 @@ Thin host layer over the C-ABI (include/pp_hip.h).  Owns nothing numerical:
 every stage runs in libpp_hip.so on the GPU; a failing call raises
 RuntimeError carrying pp_last_error().
 """
+import collections
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -47,9 +49,16 @@ class Staging:
         self.array = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), shape=(max(nbytes // 4, 1),))
         self.points = None
         self.offsets = None
+        self._users = weakref.WeakSet()     # engines that were handed this buffer (zero-copy passes read it late)
 
     def close(self):
+        """Frees the buffer -- after every engine that was fed from it has finished the pass that reads it (small
+        batches are not copied: the pass's first kernel reads this memory over the host link)."""
         if self._p:
+            for eng in list(self._users):
+                if getattr(eng, "_h", None):
+                    eng.sync()
+            self._users.clear()
             self.array = self.points = None
             self._lib.pp_host_free(self._p)
             self._p = None
@@ -95,6 +104,7 @@ class Engine:
             msg = self._lib.pp_last_error(None)
             raise RuntimeError(f"pp_create failed ({_STATUS.get(st, st)}): {msg.decode() if msg else ''}")
         self._h = h
+        self._staged = collections.deque(maxlen=2)   # Stagings of the last two upload_async calls (see there)
         self.anchors = build_anchors(d)
         self.anchor_cells = build_anchor_cells(self.anchors, d)
         self._check(self._lib.pp_set_anchors(self._h, _ptr(self.anchors), _ptr(self.anchor_cells),
@@ -115,8 +125,10 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.pp_destroy(self._h)
+            self._lib.pp_destroy(self._h)      # waits for the handle's streams
             self._h = None
+        if getattr(self, "_staged", None) is not None:
+            self._staged.clear()
 
     def __del__(self):
         try:
@@ -237,6 +249,13 @@ class Engine:
         buffer must not be rewritten before the sync() that follows the detect_async() consuming it."""
         self._check(self._lib.pp_upload_points_async(self._h, _ptr(staging.points), _ptr(staging.offsets),
                                                      staging.offsets.shape[0] - 1), "pp_upload_points_async")
+        # The handle's two input buffers alternate and the library waits for the pass that read a buffer before it
+        # re-stages it, so the buffers of the last two uploads are the ones a pass may still read: the engine keeps
+        # them alive (a temporary Staging would otherwise be freed under the zero-copy kernel).
+        users = getattr(staging, "_users", None)     # (anything with .points / .offsets may be passed)
+        if users is not None:
+            users.add(self)
+        self._staged.append(staging)
 
     def upload_device(self, dev_ptr, offsets, producer_stream=None):
         """dev_ptr: integer device address of concatenated [sum N, F] float32 points.  producer_stream: integer
@@ -383,6 +402,12 @@ class Engine:
                                                         ctypes.byref(st)), "pp_train_layout_entry")
             out.append((name.value.decode(), off.value, size.value, bool(st.value)))
         return out, npar.value, nst.value
+
+    def train_graph_stats(self):
+        """(captures, replays) of pp_train_step's hipGraphs: steady-state steps must replay."""
+        c, r = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._check(self._lib.pp_train_graph_stats(self._h, ctypes.byref(c), ctypes.byref(r)), "pp_train_graph_stats")
+        return c.value, r.value
 
     def train_step(self, params_ptr, grads_ptr, state_ptr, labels, reg_targets):
         """Forward (training mode) + loss + backward on the resident frames (pp_train_step).  The three pointers

@@ -30,16 +30,24 @@ class Trainer:
         self.grads = torch.zeros_like(self.params)
         self.state = torch.zeros(n_state, dtype=torch.float32, device=self.device)
         self.set_weights(weights)
-        tc = config.get("train_config", {}) if isinstance(config, dict) else {}
+        # train_config absent: the shipped YAML's values (configs/train.yaml: learning rate 2e-4, weight decay 1e-4).
+        # train_config present but without the keys train.py:224-239 reads: an error, not a silent default.
+        tc = config.get("train_config") if isinstance(config, dict) else None
         if learning_rate is None:
-            try:
-                learning_rate = optim.ExponentialDecay.from_config(tc, max_batch or d.batch_size)
-            except (KeyError, TypeError):
+            if tc:
+                try:
+                    learning_rate = optim.ExponentialDecay.from_config(tc, max_batch or d.batch_size)
+                except (KeyError, TypeError) as ex:
+                    raise ValueError(f"train_config: learning-rate schedule keys missing or malformed ({ex!r})") from ex
+            else:
                 learning_rate = 2e-4
         if weight_decay is None:
-            try:
-                weight_decay = float(tc["optimizer"]["adam_optimizer"]["weight_decay"])
-            except (KeyError, TypeError):
+            if tc:
+                try:
+                    weight_decay = float(tc["optimizer"]["adam_optimizer"]["weight_decay"])
+                except (KeyError, TypeError) as ex:
+                    raise ValueError(f"train_config: optimizer.adam_optimizer.weight_decay missing or malformed ({ex!r})") from ex
+            else:
                 weight_decay = 1e-4
         self.optimizer = optim.AdamW(self.params, learning_rate, weight_decay)
 
@@ -81,11 +89,18 @@ class Trainer:
         return self.engine.train_step(self.params.data_ptr(), self.grads.data_ptr(), self.state.data_ptr(), labels,
                                       reg_targets)
 
-    def step(self, frames, labels, reg_targets, dist=None):
-        out = self.forward_backward(frames, labels, reg_targets)
+    def apply_gradients(self, dist=None):
+        """optimizer.apply_gradients (train.py:301) after the data-parallel mean of the flat gradient buffer.  The
+        all-reduce and the AdamW kernel run on torch's current stream, the next pp_train_step on the engine's own
+        (non-blocking) stream: this returns only when both are through, so the next step can neither overwrite
+        gradients that are still being reduced nor read half-updated parameters."""
         optim.allreduce_gradients(self.grads, dist)        # one collective per step over the flat buffer
         self.optimizer.apply_gradients(self.grads)
         self.torch.cuda.current_stream(self.device).synchronize()
+
+    def step(self, frames, labels, reg_targets, dist=None):
+        out = self.forward_backward(frames, labels, reg_targets)
+        self.apply_gradients(dist)
         return out
 
     def close(self):

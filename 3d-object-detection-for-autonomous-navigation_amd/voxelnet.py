@@ -94,9 +94,7 @@ class VoxelNet:
 
     def apply_gradients(self, dist=None):
         """optimizer.apply_gradients (train.py:301) on the flat buffers, after the data-parallel all-reduce."""
-        from . import optim
-        optim.allreduce_gradients(self.trainer.grads, dist)
-        self.trainer.optimizer.apply_gradients(self.trainer.grads)
+        self.trainer.apply_gradients(dist)      # ends with a stream synchronisation (see Trainer.apply_gradients)
 
     def get_weights(self):
         return self.trainer.weights() if self.training else None

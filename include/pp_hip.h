@@ -303,6 +303,10 @@ int pp_train_layout_entry(pp_handle h, int32_t i, const char** name, int64_t* of
 int pp_train_step(pp_handle h, const float* params_dev, float* grads_dev, float* state_dev, const int32_t* labels,
                   const float* reg_targets, int32_t batch, const pp_loss_config* cfg, float* losses);
 
+/* How often pp_train_step captured a hipGraph and how often it replayed one (one graph per input buffer of the
+ * handle): steady-state steps must replay -- a regression check, not part of the reference's surface. */
+int pp_train_graph_stats(pp_handle h, int32_t* captures, int32_t* replays);
+
 /* Device properties for reports: name (<=255 chars), CU count, bytes of HBM. */
 int pp_device_info(pp_handle h, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes);
 /* Bytes of HBM currently free on the handle's device (hipMemGetInfo): leak checks, sizing. */

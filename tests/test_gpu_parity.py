@@ -33,7 +33,7 @@ def engines(pp, hip_lib):
         if key not in cache:
             eng = pp.Engine(cfg, max_batch=max_batch, max_points_per_frame=nmax)
             if weights_seed is not None:
-                eng.load_weights(util_ref.scale_heads(pp.weights.init_weights(eng.d, seed=weights_seed)))
+                eng.load_weights(pp.weights.init_weights(eng.d, seed=weights_seed))
             cache[key] = eng
         return cache[key]
 
@@ -115,7 +115,7 @@ def test_forward_matches_oracle(pp, engines, name, nframes, npts):
     cfg = pp.config.tiny_config(nframes) if name == "tiny" else pp.config.pedestrian_d435i_config(nframes)
     eng = engines(f"net-{name}", cfg, max_batch=nframes, weights_seed=7)
     d = eng.d
-    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=7))
+    w = pp.weights.init_weights(d, seed=7)
     if name == "tiny":
         rng = np.random.default_rng(9)
         frames = [rng.uniform([0, -0.64, -3], [1.6, 0.64, 3], (npts, 3)).astype(np.float32) for _ in range(nframes)]
@@ -129,7 +129,7 @@ def test_forward_matches_oracle(pp, engines, name, nframes, npts):
     np.testing.assert_allclose(out["canvas"], ref["canvas"], rtol=1e-5, atol=1e-5)
     for k in ("box_preds", "cls_preds", "dir_cls_preds"):
         assert out[k].shape == ref["preds"][k].shape
-        np.testing.assert_allclose(out[k], ref["preds"][k], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(out[k], ref["preds"][k], rtol=0, atol=TOL)
     # shared (y, x) across z-cells must have been summed (tf.scatter_nd semantics)
     yx = ex[2][:, 0] * 10**6 + ex[2][:, 2] * 1000 + ex[2][:, 3]
     if name == "A":
@@ -152,7 +152,7 @@ def test_small_map_split_k_kernel_ragged_tiles(pp, engines):
     assert (d.nx, d.ny) == (28, 20)
     tags = eng.layer_tags()
     assert any(t.startswith("k_sep_k4") for t in tags) and any(t.startswith("k_deconv_k4") for t in tags), tags
-    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=11))
+    w = pp.weights.init_weights(d, seed=11)
     rng = np.random.default_rng(21)
     frames = [rng.uniform([0, -0.8, -3], [2.24, 0.8, 3], (n, 3)).astype(np.float32) for n in (3000, 1700)]
     rect, trv, p2 = pp.synth.default_calib()
@@ -161,7 +161,7 @@ def test_small_map_split_k_kernel_ragged_tiles(pp, engines):
     out = eng.forward_voxels(ex[0], ex[1], ex[2], B)
     for k in ("box_preds", "cls_preds", "dir_cls_preds"):
         assert out[k].shape == ref["preds"][k].shape
-        np.testing.assert_allclose(out[k], ref["preds"][k], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(out[k], ref["preds"][k], rtol=0, atol=TOL)
 
 
 # ------------------------------------------------------------------ a8-a12
@@ -173,9 +173,9 @@ def _assert_dets(pp_dicts, ref_dicts):
             continue
         assert a["scores"] is not None
         assert a["scores"].shape == b["scores"].shape
-        np.testing.assert_allclose(a["scores"], b["scores"], rtol=TOL, atol=TOL)
-        np.testing.assert_allclose(a["box3d_lidar"], b["box3d_lidar"], rtol=TOL, atol=TOL)
-        np.testing.assert_allclose(a["box3d_camera"], b["box3d_camera"], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(a["scores"], b["scores"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(a["box3d_lidar"], b["box3d_lidar"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(a["box3d_camera"], b["box3d_camera"], rtol=0, atol=TOL)
         assert a["box3d_camera"].dtype == np.float64 and a["box3d_lidar"].dtype == np.float32
         assert np.array_equal(a["label_preds"], b["label_preds"])
         assert np.array_equal(a["bbox"], b["bbox"])
@@ -186,7 +186,7 @@ def test_predict_matches_oracle_on_oracle_preds(pp, hip_lib):
     cfg = pp.config.pedestrian_d435i_config(2)
     net = pp.VoxelNet(cfg, None, training=False, max_batch=2)
     d = net.d
-    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=7))
+    w = pp.weights.init_weights(d, seed=7)
     net.load_weights(w)
     frames = [pp.synth.d435i_cloud(40 + i) for i in range(2)]
     rect, trv, p2 = pp.synth.default_calib()
@@ -261,7 +261,7 @@ def test_config0_variant_t100_12000(pp, engines):
     cfg = pp.config.pedestrian_d435i_config(1, max_points=100, max_voxels=12000)
     eng = engines("net-A1-T100", cfg, max_batch=1, weights_seed=7)
     d = eng.d
-    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=7))
+    w = pp.weights.init_weights(d, seed=7)
     frames = [pp.synth.d435i_cloud(77)]
     rect, trv, p2 = pp.synth.default_calib()
     ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
@@ -270,7 +270,7 @@ def test_config0_variant_t100_12000(pp, engines):
     P = ref["frames"][0]["coordinates"].shape[0]
     assert im["n_pillars"][0] == P and np.array_equal(im["num_points"][0, :P], ref["frames"][0]["num_points"])
     for k in ("box_preds", "cls_preds", "dir_cls_preds"):
-        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=0, atol=TOL)
     _assert_dets([pp.VoxelNet._to_dict(dets[0], int(n[0]), 0)], ref["dets"])
 
 
@@ -281,7 +281,7 @@ def test_fused_detect_matches_oracle_end_to_end(pp, engines, name):
     cfg = pp.config.tiny_config(B) if name == "tiny" else pp.config.pedestrian_d435i_config(B)
     eng = engines(f"net-{name}", cfg, max_batch=B, weights_seed=7)
     d = eng.d
-    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=7))
+    w = pp.weights.init_weights(d, seed=7)
     if name == "tiny":
         rng = np.random.default_rng(19)
         frames = [rng.uniform([0, -0.64, -3], [1.6, 0.64, 3], (n, 3)).astype(np.float32) for n in (700, 0, 333)]
@@ -300,7 +300,7 @@ def test_fused_detect_matches_oracle_end_to_end(pp, engines, name):
         assert np.array_equal(im["anchors_mask"][b].astype(bool), fr["anchors_mask"])
     np.testing.assert_allclose(im["canvas"], ref["canvas"], rtol=1e-5, atol=1e-5)
     for k in ("box_preds", "cls_preds", "dir_cls_preds"):
-        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=0, atol=TOL)
     from importlib import import_module
     to_dict = pp.VoxelNet._to_dict
     got = [to_dict(dets[b], int(n[b]), b) for b in range(B)]
@@ -345,7 +345,7 @@ def test_kitti_shaped_forward(pp, engines):
     B = 1
     eng = engines("net-K", pp.config.kitti_shaped_config(B), max_batch=B, weights_seed=5)
     d = eng.d
-    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=5))
+    w = pp.weights.init_weights(d, seed=5)
     frames = [pp.synth.kitti_cloud(3)]
     rect, trv, p2 = pp.synth.default_calib()
     ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
@@ -360,7 +360,7 @@ def test_kitti_shaped_forward(pp, engines):
     assert im["n_pillars"][0] == P and np.array_equal(im["coors"][0, :P], fr["coordinates"])
     assert np.array_equal(im["anchors_mask"][0].astype(bool), fr["anchors_mask"])
     for k in ("box_preds", "cls_preds", "dir_cls_preds"):
-        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=0, atol=TOL)
     got = [pp.VoxelNet._to_dict(dets[0], int(n[0]), 0)]
     _assert_dets(got, ref["dets"])
     # the compat entry (padded voxels in, head maps out) on the same sparse-canvas engine: its PFN writes the
@@ -369,7 +369,7 @@ def test_kitti_shaped_forward(pp, engines):
     out = eng.forward_voxels(ex[0], ex[1], ex[2], B, want_canvas=True)
     np.testing.assert_allclose(out["canvas"], ref["canvas"], rtol=1e-5, atol=1e-5)
     for k in ("box_preds", "cls_preds", "dir_cls_preds"):
-        np.testing.assert_allclose(out[k], ref["preds"][k], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(out[k], ref["preds"][k], rtol=0, atol=TOL)
 
 
 def test_error_behaviour(pp, engines):
@@ -535,7 +535,7 @@ def test_random_small_configs_end_to_end(seed):
     cfg = _random_config(rng, B)
     eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=8192)
     d = eng.d
-    w = util_ref.scale_heads(pp.weights.init_weights(d, seed=seed))
+    w = pp.weights.init_weights(d, seed=seed)
     eng.load_weights(w)
     lo, hi = d.pc_range[:3], d.pc_range[3:]
     frames = []
@@ -554,7 +554,7 @@ def test_random_small_configs_end_to_end(seed):
         assert np.array_equal(im["num_points"][b, :P], fr["num_points"])
         assert np.array_equal(im["anchors_mask"][b].astype(bool), fr["anchors_mask"])
     for k in ("box_preds", "cls_preds", "dir_cls_preds"):
-        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(im[k], ref["preds"][k], rtol=0, atol=TOL)
     got = [pp.VoxelNet._to_dict(dets[b], int(n[b]), b) for b in range(B)]
     _assert_dets(got, ref["dets"])
     eng.close()

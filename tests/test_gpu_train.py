@@ -165,6 +165,10 @@ def test_optimizer_steps_reduce_the_loss_and_export_to_inference(pp, hip_lib):
     losses = [tr.step(frames, labels, reg)["loss"] for _ in range(12)]
     assert losses[-1] < 0.7 * losses[0], losses
     assert tr.optimizer.iterations == 12
+    # every upload flips the handle's input buffer: one captured hipGraph per buffer, every later step a replay
+    # (round 2 kept ONE graph keyed on the buffer and re-captured ~270 nodes on every optimizer step)
+    captures, replays = tr.engine.train_graph_stats()
+    assert captures <= 2 and replays == 12, (captures, replays)
     # the trained tensors (and the updated moving statistics) load into an inference engine
     w = tr.weights()
     pp.weights.check_weights(d, w)

@@ -37,11 +37,3 @@ def oracle_detect(d, w, frames, rect, trv2c, p2, num_threads=None):
     preds, canvas, feats = oracle_forward(d, w, ex, num_threads)
     dets = rn.predict(ex, preds, d.nms_dict())
     return {"example": ex, "frames": fr, "preds": preds, "canvas": canvas, "features": feats, "dets": dets}
-
-
-def scale_heads(w, cls_scale=1.0, seed=11):
-    """Spread the synthetic logits: keeps sigmoid scores off saturation so ties
-    (whose order is implementation-defined in the reference) do not occur."""
-    w = dict(w)
-    w["rpn/conv_cls/kernel"] = (w["rpn/conv_cls/kernel"] * np.float32(cls_scale)).astype(np.float32)
-    return w

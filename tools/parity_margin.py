@@ -14,7 +14,7 @@ import util_ref  # noqa: E402
 cfg = pp_amd.config.pedestrian_d435i_config(2)
 eng = pp_amd.Engine(cfg, max_batch=2, max_points_per_frame=16384)
 d = eng.d
-w = util_ref.scale_heads(pp_amd.weights.init_weights(d, seed=7))
+w = pp_amd.weights.init_weights(d, seed=7)
 eng.load_weights(w)
 frames = [pp_amd.synth.d435i_cloud(40 + i) for i in range(2)]
 rect, trv, p2 = pp_amd.synth.default_calib()
