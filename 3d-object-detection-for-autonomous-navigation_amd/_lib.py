@@ -30,7 +30,7 @@ EXPORTS = [
     "pp_upload_points", "pp_upload_points_async", "pp_host_alloc", "pp_host_free", "pp_upload_points_device",
     "pp_current_batch", "pp_set_calib", "pp_detect_async", "pp_sync",
     "pp_get_detections", "pp_detect", "pp_fetch_intermediates", "pp_set_profiling", "pp_get_kernel_times",
-    "pp_timer_start", "pp_timer_stop", "pp_device_info", "pp_device_mem_free", "pp_bench_layer", "pp_layer_count", "pp_layer_tag",
+    "pp_timer_start", "pp_timer_stop", "pp_device_info", "pp_device_copy_bench", "pp_device_mem_free", "pp_bench_layer", "pp_layer_count", "pp_layer_tag",
     "pp_rotate_iou_eval", "pp_d3_box_overlap", "pp_head_loss", "pp_adamw_step_device",
     "pp_train_layout", "pp_train_layout_entry", "pp_train_step", "pp_train_graph_stats",
 ]
@@ -223,6 +223,7 @@ def lib():
     L.pp_timer_start.argtypes = [vp]
     L.pp_timer_stop.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.pp_device_info.argtypes = [vp, ctypes.c_char_p, i32, ctypes.POINTER(i32), ctypes.POINTER(i64)]
+    L.pp_device_copy_bench.argtypes = [vp, i64, i32, ctypes.POINTER(ctypes.c_float)]
     L.pp_device_mem_free.argtypes = [vp, ctypes.POINTER(i64)]
     L.pp_bench_layer.argtypes = [vp, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_float)]
     L.pp_layer_count.argtypes = [vp, ctypes.POINTER(i32)]

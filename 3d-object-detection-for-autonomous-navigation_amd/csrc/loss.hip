@@ -43,9 +43,9 @@ __global__ __launch_bounds__(LT) void k_loss_count(const int* __restrict__ label
     }
 }
 
-// NAPL: anchors per pixel as a compile-time constant (every index into the two 32-float rows is static:
-// they stay in registers)
-template <int NAPL>
+// NAPL / NCLS: anchors per pixel and class logits per anchor as compile-time constants (every index into the two
+// 32-float rows is static: they stay in registers).  Head row: [box NAPL*7 | cls NAPL*NCLS | dir NAPL*2 | pad].
+template <int NAPL, int NCLS>
 __global__ __launch_bounds__(LT) void k_loss_pixels(LossParams p) {
     __shared__ double s_red[LT / 64][LOSS_NSUM];
     // the workgroup's 256 head rows pass through LDS: coalesced 16-byte global accesses on one side (a
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(LT) void k_loss_pixels(LossParams p) {
     const int b = blockIdx.y;
     const int px0 = blockIdx.x * LT;
     const int px = px0 + threadIdx.x;
-    constexpr int napl = NAPL, nb = NAPL * 7, nc = NAPL;
+    constexpr int napl = NAPL, nb = NAPL * 7, nc = NAPL * NCLS;
     double acc[LOSS_NSUM] = {0.0, 0.0, 0.0, 0.0, 0.0};
     const int nrows = min(LT, p.npx - px0);
     {
@@ -84,10 +84,12 @@ __global__ __launch_bounds__(LT) void k_loss_pixels(LossParams p) {
             const size_t a = (size_t)px * napl + r;
             const int label = p.labels[(size_t)b * p.A + a];
             const float pos = label > 0 ? 1.f : 0.f, neg = label == 0 ? 1.f : 0.f;
-            // ---- classification: sigmoid focal loss on the one-hot target without the background column ----
-            {
-                const float x = hrow[nb + r];
-                const float t = pos;                                     // labels * cared, one class
+            // ---- classification: sigmoid focal loss on the one-hot target without the background column
+            // (create_loss: one_hot(labels * cared, num_class + 1)[..., 1:]; class k is logit column k - 1) ----
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) {
+                const float x = hrow[nb + r * NCLS + c];
+                const float t = (label == c + 1) ? 1.f : 0.f;
                 const float w = (neg * p.neg_cls_weight + pos * p.pos_cls_weight) / norm;
                 const float ce = fminf(fmaxf(x, 0.f), 10000.f) - x * t + log1pf(expf(-fabsf(x)));
                 const float pr = 1.f / (1.f + expf(-x));
@@ -97,12 +99,18 @@ __global__ __launch_bounds__(LT) void k_loss_pixels(LossParams p) {
                 const float aw = (p.alpha >= 0.f) ? (t * p.alpha + (1.f - t) * (1.f - p.alpha)) : 1.f;
                 const float l = mod * aw * ce * w;
                 acc[1] += (double)l;
-                acc[3] += (double)(pos * l);
-                acc[4] += (double)(neg * l);
+                if (NCLS == 1) {                 // _get_pos_neg_loss (model/voxelnet.py:48-61): by the anchor's label ...
+                    acc[3] += (double)(pos * l);
+                    acc[4] += (double)(neg * l);
+                } else if (c == 0) {             // ... or, with several class columns, column 0 against the rest
+                    acc[4] += (double)l;
+                } else {
+                    acc[3] += (double)l;
+                }
                 // d/dx: ce' = sigmoid(x) - t (inside the clip range); (1 - p_t)' = (1 - 2t) p (1 - p)
                 float dmod = 0.f;
                 if (p.gamma != 0.f) dmod = p.gamma * powf(om, p.gamma - 1.f) * (1.f - 2.f * t) * pr * (1.f - pr);
-                grow[nb + r] = w * aw * (dmod * ce + mod * (pr - t)) * inv_b * p.cls_weight;
+                grow[nb + r * NCLS + c] = w * aw * (dmod * ce + mod * (pr - t)) * inv_b * p.cls_weight;
             }
             // ---- localisation: smooth L1 (sigma) on the code, the angle through sin(a - b) = sin a cos b - cos a sin b ----
             {
@@ -210,15 +218,30 @@ __global__ __launch_bounds__(64) void k_loss_finish(LossParams p, int nblocks) {
 
 int loss_blocks(int npx) { return (npx + LT - 1) / LT; }
 
+template <int NAPL>
+static int launch_pixels(const LossParams& p, dim3 grid, hipStream_t s) {
+    switch (p.ncls) {
+        case 1: hipLaunchKernelGGL((k_loss_pixels<NAPL, 1>), grid, dim3(LT), 0, s, p); return 0;
+        case 2: hipLaunchKernelGGL((k_loss_pixels<NAPL, 2>), grid, dim3(LT), 0, s, p); return 0;
+        case 3: hipLaunchKernelGGL((k_loss_pixels<NAPL, 3>), grid, dim3(LT), 0, s, p); return 0;
+        case 4: hipLaunchKernelGGL((k_loss_pixels<NAPL, 4>), grid, dim3(LT), 0, s, p); return 0;
+        default: return PP_ERR_UNSUPPORTED;
+    }
+}
+
 int launch_head_loss(const LossParams& p, hipStream_t s) {
     if (p.batch <= 0) return 0;
-    if (p.napl < 1 || p.napl > 3) return PP_ERR_UNSUPPORTED;   // 10 head columns per anchor, 32 per row
+    // 7 + ncls + 2 head columns per anchor (the direction pair only with the direction head), 32 per row
+    if (p.napl < 1 || p.napl > 3 || p.ncls < 1 || p.ncls > 4 ||
+        p.napl * (7 + p.ncls + (p.use_direction ? 2 : 0)) > PP_HEAD_COLS) return PP_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_loss_count, dim3(p.batch), dim3(LT), 0, s, p.labels, p.A, p.npos);
     const int nblocks = loss_blocks(p.npx);
     const dim3 grid(nblocks, p.batch);
-    if (p.napl == 1) hipLaunchKernelGGL(k_loss_pixels<1>, grid, dim3(LT), 0, s, p);
-    else if (p.napl == 2) hipLaunchKernelGGL(k_loss_pixels<2>, grid, dim3(LT), 0, s, p);
-    else hipLaunchKernelGGL(k_loss_pixels<3>, grid, dim3(LT), 0, s, p);
+    int st;
+    if (p.napl == 1) st = launch_pixels<1>(p, grid, s);
+    else if (p.napl == 2) st = launch_pixels<2>(p, grid, s);
+    else st = launch_pixels<3>(p, grid, s);
+    if (st) return st;
     hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, s, p, nblocks);
     return 0;
 }

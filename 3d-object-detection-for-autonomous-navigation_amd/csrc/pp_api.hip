@@ -1607,7 +1607,7 @@ int ensure_loss_buffers(pp_engine* e) {
 
 void fill_loss_params(pp_engine* e, const pp_loss_config* lc, int batch, LossParams& p) {
     memset(&p, 0, sizeof(p));
-    p.batch = batch; p.A = e->A; p.npx = e->head_h * e->head_w; p.napl = e->napl;
+    p.batch = batch; p.A = e->A; p.npx = e->head_h * e->head_w; p.napl = e->napl; p.ncls = e->ncls;
     p.head = e->d_head; p.labels = e->d_loss_labels; p.reg_targets = e->d_loss_regt; p.anchors = e->d_anchors;
     p.npos = e->d_loss_npos; p.partials = e->d_loss_partials; p.losses = e->d_loss_out;
     p.alpha = lc->alpha; p.gamma = lc->gamma; p.sigma = lc->sigma;
@@ -1675,6 +1675,14 @@ int train_buffers(pp_engine* e) {
     A1(dalloc(e, &cx.dhead_w, (size_t)s.CC * PP_HEAD_COLS)); A1(dalloc(e, &cx.dhead_b, (size_t)2 * PP_HEAD_COLS));
     A1(dalloc(e, &cx.dZ, max_z)); A1(dalloc(e, &cx.dD, max_d));
     A1(dalloc(e, &cx.part, train_part_floats(s)));
+    {   // one [2][N] row per 64-row tile of the largest forward product
+        size_t need = 1;
+        for (const LayerDesc& l : s.layers) {
+            if (l.kind == LAYER_SEP) need = std::max(need, (B * l.out_h * l.out_w + 63) / 64 * 2 * (size_t)l.cout);
+            else if (l.kind == LAYER_DECONV) need = std::max(need, (B * l.in_h * l.in_w + 63) / 64 * 2 * (size_t)l.k * l.k * l.cout);
+        }
+        A1(dalloc(e, &cx.stat_part, need));
+    }
     cx.gemm_part_floats = 16l << 20;   // 64 MB of split-K partial tiles
     A1(dalloc(e, &cx.gemm_part, (size_t)cx.gemm_part_floats));
     if (st == PP_OK) st = ensure_loss_buffers(e);
@@ -1692,7 +1700,8 @@ int pp_head_loss(pp_handle e, const int32_t* labels, const float* reg_targets, i
     int st = check_batch(e, batch);
     if (st) return st;
     if (!(lc->sigma > 0.f)) return fail(e, PP_ERR_ARG, "pp_head_loss: sigma must be positive");
-    if (e->cfg.num_class != 1 || !e->use_dir) return fail(e, PP_ERR_UNSUPPORTED, "pp_head_loss: one class with the direction head only (the shipped training config)");
+    if ((lc->use_direction_classifier != 0) != e->use_dir)
+        return fail(e, PP_ERR_ARG, "pp_head_loss: loss config and engine disagree on use_direction_classifier");
     (void)hipSetDevice(e->device);
     const size_t npx = (size_t)e->head_h * e->head_w;
     if ((st = ensure_loss_buffers(e))) return st;
@@ -1703,7 +1712,7 @@ int pp_head_loss(pp_handle e, const int32_t* labels, const float* reg_targets, i
     p.head_grad = head_grad ? e->d_head_grad : nullptr;
     {
         ProfScope ps(e, "k_loss_pixels:loss+grad", true);
-        if ((st = launch_head_loss(p, e->stream))) return fail(e, st, "pp_head_loss: %d anchors per pixel not supported", e->napl);
+        if ((st = launch_head_loss(p, e->stream))) return fail(e, st, "pp_head_loss: %d anchors per pixel x %d classes not supported", e->napl, e->ncls);
     }
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipMemcpyAsync(losses, e->d_loss_out, 8 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -1742,8 +1751,8 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
     if (!e->anchors_ready) return fail(e, PP_ERR_STATE, "pp_train_step: anchors not set");
     if (e->cur_batch < 1 || e->cur_batch != batch)
         return fail(e, PP_ERR_STATE, "pp_train_step: %d frames are resident, batch is %d (upload the frames first)", e->cur_batch, batch);
-    if (e->cfg.num_class != 1 || !e->use_dir)
-        return fail(e, PP_ERR_UNSUPPORTED, "pp_train_step: one class with the direction head only (the shipped training config)");
+    if ((lc->use_direction_classifier != 0) != e->use_dir)
+        return fail(e, PP_ERR_ARG, "pp_train_step: loss config and engine disagree on use_direction_classifier");
     if (!(lc->sigma > 0.f)) return fail(e, PP_ERR_ARG, "pp_train_step: sigma must be positive");
     (void)hipSetDevice(e->device);
     int st = train_state(e); if (st) return st;
@@ -1843,6 +1852,34 @@ int pp_device_mem_free(pp_handle e, int64_t* free_bytes) {
     size_t fr = 0, tot = 0;
     HIPCHK(e, hipMemGetInfo(&fr, &tot));
     *free_bytes = (int64_t)fr;
+    return PP_OK;
+}
+
+// measurement helper: device-to-device copy rate on the handle's stream (the bench states the HBM figure it
+// measured in the run beside the spec constant its roofline fractions use)
+int pp_device_copy_bench(pp_handle e, int64_t bytes, int32_t reps, float* gbytes_per_s) {
+    if (!e || !gbytes_per_s || bytes <= 0 || reps <= 0) return fail(e, PP_ERR_ARG, "pp_device_copy_bench: bad argument");
+    (void)hipSetDevice(e->device);
+    void *src = nullptr, *dst = nullptr;
+    if (hipMalloc(&src, (size_t)bytes) != hipSuccess || hipMalloc(&dst, (size_t)bytes) != hipSuccess) {
+        if (src) (void)hipFree(src);
+        (void)hipGetLastError();
+        return fail(e, PP_ERR_HIP, "pp_device_copy_bench: hipMalloc(2 x %lld) failed", (long long)bytes);
+    }
+    int st = PP_OK;
+    float ms = 0.f;
+    if (hipMemsetAsync(src, 1, (size_t)bytes, e->stream) != hipSuccess ||
+        hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, e->stream) != hipSuccess ||     // warm-up
+        hipEventRecord(e->t0, e->stream) != hipSuccess) st = PP_ERR_HIP;
+    for (int i = 0; i < reps && st == PP_OK; ++i)
+        if (hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, e->stream) != hipSuccess) st = PP_ERR_HIP;
+    if (st == PP_OK && (hipEventRecord(e->t1, e->stream) != hipSuccess || hipEventSynchronize(e->t1) != hipSuccess ||
+                        hipEventElapsedTime(&ms, e->t0, e->t1) != hipSuccess)) st = PP_ERR_HIP;
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    if (st != PP_OK) { (void)hipGetLastError(); return fail(e, st, "pp_device_copy_bench: copy failed"); }
+    *gbytes_per_s = (float)(2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9);   // read + write
     return PP_OK;
 }
 

@@ -174,6 +174,7 @@ struct LossParams {
     int batch;
     int64_t A;             // anchors per frame
     int npx, napl;         // head pixels per frame, anchors per pixel
+    int ncls;              // class logits per anchor (num_class; the background column is not encoded)
     const float* head;     // [batch][npx][PP_HEAD_COLS]
     const int* labels;     // [batch][A]  (>0 class, 0 background, -1 ignored)
     const float* reg_targets;  // [batch][A][7]

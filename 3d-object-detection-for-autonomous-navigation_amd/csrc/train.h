@@ -60,6 +60,7 @@ struct TrainCtx {
     float* dZ;           // scratch [max rows * cout]
     float* dD;           // scratch [max rows * cin]
     float* part;         // partial sums of the persistent reductions
+    float* stat_part;    // BatchNorm statistics partials of the forward products: [row tiles][2][GEMM columns]
     float* gemm_part;    // split-K partial tiles
     long gemm_part_floats;
 };

@@ -36,7 +36,12 @@
 typedef float tf32x16 __attribute__((ext_vector_type(16)));
 
 #define TR_EPS 1e-3f
-#define TR_NPART 256   // workgroups of the persistent reduction kernels (= rows of their partial-sum buffers)
+// workgroups of the persistent reduction kernels (= rows of their partial-sum buffers): one per CU for the reference's
+// 2-frame batches (every launch is a few microseconds: more workgroups only add dispatch time), up to TR_NPART_MAX
+// for large per-GPU batches, where 256 workgroups leave the chip a quarter full.  Chosen per step by train_step.
+#define TR_NPART_MAX 2048
+static int g_tr_npart = 256;
+#define TR_NPART g_tr_npart
 
 // ------------------------------------------------------------------------------------------------------------
 // float32 MFMA GEMM:  C[M][N] (+)= A(m,k) * B(k,n) [+ bias(n)],  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
@@ -119,32 +124,304 @@ __global__ __launch_bounds__(256) void k_tr_gemm(TGemm g) {
     }
 }
 
-// out[i] (+)= scale * sum_p part[p][i] in a fixed order (deterministic): 16 lanes share an output element, lane l
-// adds parts l, l + 16, ... and the 16 lane sums are added by a shuffle tree
-__global__ __launch_bounds__(256) void k_tr_reduce(const float* __restrict__ part, int nparts, long n, long pstride,
-                                                   float* __restrict__ out, long ldo, int ncols, int accumulate, float scale) {
-    const int l = threadIdx.x & 15;
-    const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    float s = 0.f;
-    if (i < n)
-        for (int p = l; p < nparts; p += 16) s += part[(size_t)p * pstride + i];
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    if (i >= n || l != 0) return;
-    s *= scale;
-    // optional re-striding of the output ([rows][ncols] with leading dimension ldo)
-    float* o = (ncols > 0) ? out + (i / ncols) * ldo + (i % ncols) : out + i;
-    *o = accumulate ? (*o + s) : s;
+// ------------------------------------------------------------------------------------------------------------
+// Split-precision GEMM (round 3): the same C = A . B contract as k_tr_gemm on the 16-bit matrix pipe.  Every
+// float32 operand value is carried as THREE bfloat16 pieces (hi + mid + lo: 24 significand bits, float32's exponent
+// range -- gradients of 1e-8 and activations of 1e3 alike) and a product as the six piece products of weight
+// >= 2^-16, accumulated in float32: float32-equivalent results (the inference kernels' PP_SPLIT_MODE 0 arithmetic)
+// at 6 x 32 matrix-pipe cycles per 32x32x16 block instead of 8 x 64 with v_mfma_f32_32x32x2_f32.
+//   * a 4-wave workgroup owns a (64*WM) x (64*WN) tile, wave (wm, wn) a (32*WM) x (32*WN) part of it; K in chunks
+//     of 32 through LDS, the next chunk's global loads (16 bytes per lane) in flight while the current one is
+//     multiplied;
+//   * the split happens ONCE per loaded element, on the way into LDS (three planes of [rows][32 + 8 pad] bfloat16:
+//     80-byte rows make the 16-byte fragment reads conflict-free); an operand whose unit-stride axis is not K
+//     (TN / NT forms: weight gradients, transposed weights) is transposed in registers on that way;
+//   * epilogue: bias, accumulate into C, split-K partial tiles (reduced by k_tr_reduce in a fixed order), and --
+//     for the forward products that feed a BatchNorm -- the per-column sum and sum of squares of the workgroup's
+//     rows (statistics partials [row tile][2][N]: k_tr_colstats' pass over Z is gone).
+// AKC: A(m, k) has unit stride along k (sak == 1), else along m (sam == 1);  BKC: B(k, n) along k, else along n.
+// Needs K % 4 == 0, 16-byte aligned rows (leading dimensions % 4 == 0); the launcher falls back to k_tr_gemm.
+// ------------------------------------------------------------------------------------------------------------
+typedef __bf16 tbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 tbf16x2 __attribute__((ext_vector_type(2)));
+typedef float tf32x2 __attribute__((ext_vector_type(2)));
+#define T2_LDR 40                         // bfloat16 per LDS row: 32 of the chunk + 8 pad (80 bytes)
+
+// v[0..1] -> packed bfloat16 pairs of the three pieces
+__device__ __forceinline__ void t2_split2(float v0, float v1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const tf32x2 x = {v0, v1};
+    const tbf16x2 h = __builtin_convertvector(x, tbf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const tf32x2 r1 = {v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u)};
+    const tbf16x2 m = __builtin_convertvector(r1, tbf16x2);
+    mid = __builtin_bit_cast(unsigned, m);
+    const tf32x2 r2 = {r1.x - __uint_as_float(mid << 16), r1.y - __uint_as_float(mid & 0xffff0000u)};
+    const tbf16x2 l = __builtin_convertvector(r2, tbf16x2);
+    lo = __builtin_bit_cast(unsigned, l);
 }
 
-static unsigned reduce_blocks(long n) { return (unsigned)((n + 15) / 16); }
+// One operand tile of ROWS (m or n) x 32 (k) per chunk, 256 threads.  KC form: a thread owns EPT consecutive k of one
+// row; transposed form: 4 consecutive rows x EPT / 4 consecutive k.
+template <int ROWS, bool KC>
+struct T2Stage {
+    static constexpr int EPT = ROWS / 8;                   // elements per thread per chunk: 16 (128 rows) or 8 (64)
+    float v[EPT];
+    // p(r, k) = base[r * sr + k * sk]; rows >= nrows and k >= kend read as zero
+    __device__ __forceinline__ void load(const float* __restrict__ base, long sr, long sk, int row0, int nrows, int k0, int kend, int tid) {
+        if (KC) {
+            constexpr int TPR = 32 / EPT;
+            const int r = row0 + tid / TPR, k = k0 + (tid % TPR) * EPT;
+            const float* q = base + (long)r * sr + k;
+#pragma unroll
+            for (int j = 0; j < EPT; j += 4) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < nrows && k + j < kend) t = *reinterpret_cast<const float4*>(q + j);     // K % 4 == 0
+                v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+            }
+        } else {
+            constexpr int KPT = EPT / 4, RG = ROWS / 4;    // k per thread; groups of 4 rows
+            const int r = row0 + (tid % RG) * 4, k = k0 + (tid / RG) * KPT;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < nrows && k + j < kend) t = *reinterpret_cast<const float4*>(base + (long)(k + j) * sk + r);   // rows % 4 == 0
+                v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;   // v[4j + i] = p(r + i, k + j)
+            }
+        }
+    }
+    // split and store into the three LDS planes plane[p][row][T2_LDR]
+    __device__ __forceinline__ void store(__bf16* __restrict__ lds, int tid) const {
+        constexpr int PL = ROWS * T2_LDR;
+        if (KC) {
+            constexpr int TPR = 32 / EPT;
+            __bf16* d = lds + (tid / TPR) * T2_LDR + (tid % TPR) * EPT;
+#pragma unroll
+            for (int j = 0; j < EPT; j += 8) {
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t2_split2(v[j + 2 * i], v[j + 2 * i + 1], h[i], m[i], l[i]);
+                *reinterpret_cast<uint4*>(d + j) = make_uint4(h[0], h[1], h[2], h[3]);
+                *reinterpret_cast<uint4*>(d + PL + j) = make_uint4(m[0], m[1], m[2], m[3]);
+                *reinterpret_cast<uint4*>(d + 2 * PL + j) = make_uint4(l[0], l[1], l[2], l[3]);
+            }
+        } else {
+            constexpr int KPT = EPT / 4, RG = ROWS / 4;
+            __bf16* d = lds + ((tid % RG) * 4) * T2_LDR + (tid / RG) * KPT;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                  // row r + i: KPT consecutive k
+                unsigned h[KPT / 2], m[KPT / 2], l[KPT / 2];
+#pragma unroll
+                for (int j = 0; j < KPT; j += 2) t2_split2(v[4 * j + i], v[4 * (j + 1) + i], h[j / 2], m[j / 2], l[j / 2]);
+                if (KPT == 4) {
+                    *reinterpret_cast<uint2*>(d + i * T2_LDR) = make_uint2(h[0], h[KPT / 2 - 1]);
+                    *reinterpret_cast<uint2*>(d + PL + i * T2_LDR) = make_uint2(m[0], m[KPT / 2 - 1]);
+                    *reinterpret_cast<uint2*>(d + 2 * PL + i * T2_LDR) = make_uint2(l[0], l[KPT / 2 - 1]);
+                } else {
+                    *reinterpret_cast<unsigned*>(d + i * T2_LDR) = h[0];
+                    *reinterpret_cast<unsigned*>(d + PL + i * T2_LDR) = m[0];
+                    *reinterpret_cast<unsigned*>(d + 2 * PL + i * T2_LDR) = l[0];
+                }
+            }
+        }
+    }
+};
+
+struct TGemm2 {
+    TGemm g;
+    float* stat_part;    // [gridDim.y][2][N] column sums / sums of squares of the tile's rows, or NULL
+};
+
+template <int WM, int WN, bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void k_tr_gemm2(TGemm2 a2) {
+    const TGemm& g = a2.g;
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int PLA = BM * T2_LDR, PLB = BN * T2_LDR;
+    __shared__ __attribute__((aligned(16))) __bf16 sA[3 * PLA];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[3 * PLB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, r32 = lane & 31;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kper, kend = min(g.K, kbeg + g.kper);
+    T2Stage<BM, AKC> ra;
+    T2Stage<BN, BKC> rb;
+    // A(m, k): row stride sam / k stride sak;  B(k, n) seen as rows n: row stride sbn, k stride sbk
+    tf32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (kbeg < kend) {
+        ra.load(g.A, g.sam, g.sak, m0, g.M, kbeg, kend, tid);
+        rb.load(g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid);
+    }
+    const __bf16* fa = sA + (wm * 32 * WM + r32) * T2_LDR + 8 * h;
+    const __bf16* fb = sB + (wn * 32 * WN + r32) * T2_LDR + 8 * h;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        __syncthreads();                                   // the previous chunk's fragments have been read
+        ra.store(sA, tid);
+        rb.store(sB, tid);
+        __syncthreads();
+        if (k0 + 32 < kend) {
+            ra.load(g.A, g.sam, g.sak, m0, g.M, k0 + 32, kend, tid);
+            rb.load(g.B, g.sbn, g.sbk, n0, g.N, k0 + 32, kend, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            tbf16x8 ah[WM], am[WM], al[WM];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const __bf16* q = fa + i * 32 * T2_LDR + ks * 16;
+                ah[i] = *reinterpret_cast<const tbf16x8*>(q);
+                am[i] = *reinterpret_cast<const tbf16x8*>(q + PLA);
+                al[i] = *reinterpret_cast<const tbf16x8*>(q + 2 * PLA);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const __bf16* q = fb + j * 32 * T2_LDR + ks * 16;
+                const tbf16x8 bh = *reinterpret_cast<const tbf16x8*>(q);
+                const tbf16x8 bm = *reinterpret_cast<const tbf16x8*>(q + PLB);
+                const tbf16x8 bl = *reinterpret_cast<const tbf16x8*>(q + 2 * PLB);
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {             // smallest terms first
+                    tf32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+            }
+        }
+    }
+    // D[row][col]: col = lane & 31 (n), row = (reg & 3) + 8 * (reg >> 2) + 4 * h (m)
+    if (a2.stat_part != nullptr) {      // column sums of this workgroup's rows (rows >= M are zero rows of A)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(sA);         // [2 row-waves][2][BN]
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float z = acc[i][j][r]; s1 += z; s2 = fmaf(z, z, s2); }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (h == 0) {
+                const int col = wn * 32 * WN + j * 32 + r32;
+                red[(wm * 2 + 0) * BN + col] = s1;
+                red[(wm * 2 + 1) * BN + col] = s2;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BN; e += 256) {
+            const int which = e / BN, col = e % BN;
+            if (n0 + col < g.N)
+                a2.stat_part[((size_t)blockIdx.y * 2 + which) * g.N + n0 + col] = red[which * BN + col] + red[(2 + which) * BN + col];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wn * 32 * WN + j * 32 + r32;
+        if (n >= g.N) continue;
+        const float bv = (g.bias != nullptr) ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                if (gridDim.z > 1) {
+                    g.Cpart[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+                } else {
+                    float* c = g.C + (size_t)m * g.ldc + n;
+                    const float v = acc[i][j][r] + bv;
+                    *c = g.accumulate ? (*c + v) : v;
+                }
+            }
+    }
+}
+
+// out[i] (+)= scale * sum_p part[p][i] in a fixed order (deterministic).  A workgroup owns 32 consecutive outputs
+// and cuts the partial rows into 8 interleaved slices (thread = (slice, output): a wave reads two 128-byte segments
+// per step, coalesced); slice s adds rows s, s + 8, ... in order, the 8 slice sums are added in order through LDS.
+__global__ __launch_bounds__(256) void k_tr_reduce(const float* __restrict__ part, int nparts, long n, long pstride,
+                                                   float* __restrict__ out, long ldo, int ncols, int accumulate, float scale) {
+    __shared__ float ssum[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + o;
+    float s = 0.f;
+    if (i < n)
+        for (int p = sl; p < nparts; p += 8) s += part[(size_t)p * pstride + i];
+    ssum[sl][o] = s;
+    __syncthreads();
+    if (sl != 0 || i >= n) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += ssum[k][o];
+    s *= scale;
+    // optional re-striding of the output ([rows][ncols] with leading dimension ldo)
+    float* q = (ncols > 0) ? out + (i / ncols) * ldo + (i % ncols) : out + i;
+    *q = accumulate ? (*q + s) : s;
+}
+
+static unsigned reduce_blocks(long n) { return (unsigned)((n + 31) / 32); }
+
+// PP_TRAIN_GEMM=f32 keeps every product on the float32 matrix instruction (k_tr_gemm)
+static bool train_split_gemm() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PP_TRAIN_GEMM"); v = (e && e[0] == 'f') ? 0 : 1; }
+    return v == 1;
+}
+
+template <int WM, int WN>
+static void launch_gemm2(const TGemm2& a2, bool akc, bool bkc, dim3 grid, hipStream_t s) {
+    if (akc && bkc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, true, true>), grid, dim3(256), 0, s, a2);
+    else if (akc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, true, false>), grid, dim3(256), 0, s, a2);
+    else if (bkc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, false, true>), grid, dim3(256), 0, s, a2);
+    else PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, false, false>), grid, dim3(256), 0, s, a2);
+}
+
+// rows of the statistics partials a forward product leaves ([tiles][2][N]; 0: the split kernel did not run)
+static int g_last_stat_tiles = 0;
 
 static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
-                    long ldc, int M, int N, int K, const float* bias, int accumulate, int ksplit) {
+                    long ldc, int M, int N, int K, const float* bias, int accumulate, int ksplit, float* stat_part = nullptr) {
     TGemm g;
     g.A = A; g.sam = sam; g.sak = sak; g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.accumulate = accumulate; g.Cpart = cx.gemm_part;
     if (ksplit < 1) ksplit = 1;
+    g_last_stat_tiles = 0;
+    // the split-precision kernel: unit stride on one axis of each operand, 16-byte aligned rows
+    const bool akc = sak == 1, bkc = sbk == 1;
+    const bool a_ok = akc ? (sam % 4 == 0) : (sam == 1 && sak % 4 == 0 && M % 4 == 0);
+    const bool b_ok = bkc ? (sbn % 4 == 0) : (sbn == 1 && sbk % 4 == 0 && N % 4 == 0);
+    if (train_split_gemm() && a_ok && b_ok && K % 4 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0)) {
+        int kper = ((K + ksplit - 1) / ksplit + 31) / 32 * 32;
+        ksplit = (K + kper - 1) / kper;
+        g.kper = kper;
+        TGemm2 a2{g, (ksplit == 1) ? stat_part : nullptr};
+        // big tiles when they still fill the chip, small ones otherwise
+        const long big = (long)((M + 127) / 128) * ((N + 127) / 128) * ksplit;
+        if (N >= 128 && big >= 2 * 256) {
+            dim3 grid((N + 127) / 128, (M + 127) / 128, ksplit);
+            if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
+            launch_gemm2<2, 2>(a2, akc, bkc, grid, cx.stream);
+        } else {
+            dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
+            if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
+            launch_gemm2<1, 1>(a2, akc, bkc, grid, cx.stream);
+        }
+        if (ksplit > 1) {
+            const long n = (long)M * N;
+            PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(n)), dim3(256), 0, cx.stream,
+                      (const float*)cx.gemm_part, ksplit, n, n, C, ldc, N, accumulate, 1.0f);
+        }
+        return;
+    }
     int kper = ((K + ksplit - 1) / ksplit + 15) / 16 * 16;
     ksplit = (K + kper - 1) / kper;
     g.kper = kper;
@@ -241,46 +518,54 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd_in(const float* __restrict__ 
     *dst = o;
 }
 
-// gradient of the depthwise kernel: part[blk][t][c] = sum over this workgroup's output pixels of X(window t) * dD.
-// 256 / C pixel lanes per workgroup (thread = channel x pixel lane), workgroups stride over the pixels;
-// k_tr_reduce adds the TR_NPART partial rows.
+// depthwise kernel gradient: dw[tap][c] = sum over output pixels of X[window position tap][c] * dD[pixel][c].
+// A workgroup owns a CONTIGUOUS range of output pixels (the 3x3 windows of neighbouring pixels share their loads in
+// L1 / L2); a thread owns 4 channels (16-byte loads) of every (256 / (C / 4))-th pixel of the range; the per-thread
+// sums of the 9 taps meet in LDS and leave one partial row part[blk][9][C]; k_tr_reduce adds the rows in order.
 __global__ __launch_bounds__(256) void k_tr_dw_bwd_w(const float* __restrict__ X, const float* __restrict__ dD,
                                                      float* __restrict__ part, int B, int ih, int iw, int oh, int ow,
                                                      int C, int S) {
-    __shared__ float sred[9 * 256];
+    __shared__ float4 sred[9 * 256];
     const int tid = threadIdx.x;
-    const int lanes_per_row = (C >= 256) ? 256 : C;      // C in {32, 64, 128, 256}
-    const int rsub = tid / lanes_per_row, nsub = 256 / lanes_per_row;
-    const int c = tid % lanes_per_row;
+    const int cq = C >> 2;                               // channel quads: 8 .. 64 (C in {32, 64, 128, 256})
+    const int q = tid % cq, ps = tid / cq, nps = 256 / cq;
     const long npix = (long)B * oh * ow;
-    float acc[9];
+    const long per = (npix + gridDim.x - 1) / gridDim.x;
+    const long p0 = (long)blockIdx.x * per, p1 = min(npix, p0 + per);
+    float4 acc[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-    for (long p = (long)blockIdx.x * nsub + rsub; p < npix; p += (long)gridDim.x * nsub) {
+    for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long p = p0 + ps; p < p1; p += nps) {
         const int x = (int)(p % ow);
         const int y = (int)((p / ow) % oh);
         const int b = (int)(p / ((long)ow * oh));
-        const float g = dD[(size_t)p * C + c];
+        const float4 g = *reinterpret_cast<const float4*>(dD + (size_t)p * C + 4 * q);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int yy = y * S - 1 + dy;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int xx = x * S - 1 + dx;
-                if ((unsigned)yy < (unsigned)ih && (unsigned)xx < (unsigned)iw)
-                    acc[dy * 3 + dx] = fmaf(X[(((size_t)b * ih + yy) * iw + xx) * C + c], g, acc[dy * 3 + dx]);
+                if ((unsigned)yy < (unsigned)ih && (unsigned)xx < (unsigned)iw) {
+                    const float4 v = *reinterpret_cast<const float4*>(X + (((size_t)b * ih + yy) * iw + xx) * C + 4 * q);
+                    float4& a = acc[dy * 3 + dx];
+                    a.x = fmaf(v.x, g.x, a.x); a.y = fmaf(v.y, g.y, a.y); a.z = fmaf(v.z, g.z, a.z); a.w = fmaf(v.w, g.w, a.w);
+                }
             }
         }
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t) sred[t * 256 + tid] = acc[t];
     __syncthreads();
-    if (rsub == 0) {
+    if (ps == 0) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            float v = acc[t];
-            for (int k = 1; k < nsub; ++k) v += sred[t * 256 + tid + k * lanes_per_row];
-            part[((size_t)blockIdx.x * 9 + t) * C + c] = v;
+            float4 v = acc[t];
+            for (int k = 1; k < nps; ++k) {
+                const float4 o = sred[t * 256 + tid + k * cq];
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 9 + t) * C + 4 * q) = v;
         }
     }
 }
@@ -312,20 +597,28 @@ __global__ __launch_bounds__(256) void k_tr_colstats(const float* __restrict__ Z
 // BatchNorm statistics from the per-workgroup partial sums part[p][0/1][c] (16 lanes per channel add the partial
 // rows in a fixed order -- the reduction and the finalisation in one launch): stats[c] = (mean, 1/sqrt(var + eps))
 // with the biased batch variance; moving statistics updated in place as Keras does
+// (ntaps > 1: the partial rows are [2][ntaps * C] -- a transposed convolution's GEMM columns, tap-major -- and a
+// channel's statistics run over all its taps)
+// LPC lanes share a channel (16: a handful of partial rows; 64: the many row tiles of a large batch)
+template <int LPC>
 __global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict__ part, int nparts, int C, float n_rows_arg,
                                                         const float* __restrict__ n_rows_dev, float momentum,
                                                         int unbiased_moving, float* __restrict__ stats,
-                                                        float* __restrict__ moving_mean, float* __restrict__ moving_var) {
-    const int l = threadIdx.x & 15;
-    const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+                                                        float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                        int ntaps) {
+    const int l = threadIdx.x & (LPC - 1);
+    const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     float s1 = 0.f, s2 = 0.f;
-    if (c < C)
-        for (int p = l; p < nparts; p += 16) {
-            s1 += part[((size_t)p * 2 + 0) * C + c];
-            s2 += part[((size_t)p * 2 + 1) * C + c];
-        }
+    if (c < C) {
+        const size_t N = (size_t)C * ntaps;
+        for (int p = l; p < nparts; p += LPC)
+            for (int t = 0; t < ntaps; ++t) {
+                s1 += part[((size_t)p * 2 + 0) * N + (size_t)t * C + c];
+                s2 += part[((size_t)p * 2 + 1) * N + (size_t)t * C + c];
+            }
+    }
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    for (int off = LPC / 2; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
     if (c >= C || l != 0) return;
     const float n_rows = fmaxf((n_rows_dev != nullptr) ? *n_rows_dev : n_rows_arg, 1.f);   // PFN: P * T, known on the device only
     const float mean = s1 / n_rows;
@@ -375,33 +668,49 @@ __global__ __launch_bounds__(256) void k_tr_bn_relu(const float* __restrict__ Z,
     *reinterpret_cast<float4*>(A + (size_t)map_row(rm, r) * ld + co_off + c) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// backward of BN + ReLU, pass 1: g = dA * (A > 0); part[blk][0][c] = sum g, part[blk][1][c] = sum g * zhat
+// backward of BN + ReLU, pass 1: g = dA * (A > 0); part[blk][0][c] = sum g, part[blk][1][c] = sum g * zhat.
+// A workgroup owns a contiguous range of rows, a thread 4 channels (16-byte loads) of every (256 / (C / 4))-th row.
 __global__ __launch_bounds__(256) void k_tr_bn_bwd_reduce(const float* __restrict__ dA, int ld, int co_off, RowMap rm,
                                                           const float* __restrict__ Z, long rows, int C,
                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ part) {
-    __shared__ float s1[256], s2[256];
+    __shared__ float4 s1[256], s2[256];
     const int tid = threadIdx.x;
-    const int lanes_per_row = (C >= 256) ? 256 : C;
-    const int rsub = tid / lanes_per_row, nsub = 256 / lanes_per_row;
-    for (int cb = 0; cb < C; cb += 256) {
-        const int c = cb + tid % lanes_per_row;
-        const float mean = stats[2 * c], inv = stats[2 * c + 1], ga = gamma[c], be = beta[c];
-        float a = 0.f, q = 0.f;
-        for (long r = (long)blockIdx.x * nsub + rsub; r < rows; r += (long)gridDim.x * nsub) {
-            const float zh = (Z[(size_t)r * C + c] - mean) * inv;
-            const float act = zh * ga + be;
-            const float g = (act > 0.f) ? dA[(size_t)map_row(rm, r) * ld + co_off + c] : 0.f;
-            a += g; q = fmaf(g, zh, q);
+    const int cq = C >> 2;
+    const int q = tid % cq, rs = tid / cq, nrs = 256 / cq;
+    float mean[4], inv[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * q + j;
+        mean[j] = stats[2 * c]; inv[j] = stats[2 * c + 1]; ga[j] = gamma[c]; be[j] = beta[c];
+    }
+    const long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * per, r1 = min(rows, r0 + per);
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long r = r0 + rs; r < r1; r += nrs) {
+        const float4 z4 = *reinterpret_cast<const float4*>(Z + (size_t)r * C + 4 * q);
+        const float4 d4 = *reinterpret_cast<const float4*>(dA + (size_t)map_row(rm, r) * ld + co_off + 4 * q);
+        const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float zh = (zz[j] - mean[j]) * inv[j];
+            const float act = zh * ga[j] + be[j];
+            const float g = (act > 0.f) ? dd[j] : 0.f;
+            a[j] += g; b[j] = fmaf(g, zh, b[j]);
         }
-        s1[tid] = a; s2[tid] = q;
-        __syncthreads();
-        if (rsub == 0) {
-            for (int k = 1; k < nsub; ++k) { a += s1[tid + k * lanes_per_row]; q += s2[tid + k * lanes_per_row]; }
-            part[((size_t)blockIdx.x * 2 + 0) * C + c] = a;
-            part[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
+    }
+    s1[tid] = make_float4(a[0], a[1], a[2], a[3]);
+    s2[tid] = make_float4(b[0], b[1], b[2], b[3]);
+    __syncthreads();
+    if (rs == 0) {
+        float4 v = s1[tid], w = s2[tid];
+        for (int k = 1; k < nrs; ++k) {
+            const float4 o = s1[tid + k * cq], u = s2[tid + k * cq];
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w;
         }
-        __syncthreads();
+        *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + 4 * q) = v;
+        *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + 4 * q) = w;
     }
 }
 
@@ -784,18 +1093,33 @@ struct Lookup {
 
 unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
 
+// statistics from `nparts` partial rows [2][C * ntaps]
+static void bn_finalize(const TrainCtx& cx, const float* part, int nparts, int C, float n_rows, const float* n_rows_dev,
+                        float momentum, int unbiased, float* stats, float* mmean, float* mvar, int ntaps) {
+    if ((long)nparts * ntaps >= 512)
+        PP_LAUNCH("k_tr_bn_finalize", (k_tr_bn_finalize<64>), dim3((C + 3) / 4), dim3(256), 0, cx.stream, part, nparts, C, n_rows,
+                  n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps);
+    else
+        PP_LAUNCH("k_tr_bn_finalize", (k_tr_bn_finalize<16>), dim3((C + 15) / 16), dim3(256), 0, cx.stream, part, nparts, C, n_rows,
+                  n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps);
+}
+
 void col_reduce(const TrainCtx& cx, int C, float* sums) {   // TR_NPART partial rows of [2][C] -> sums[2][C]
     PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(2 * C)), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
               (long)2 * C, (long)2 * C, sums, 0L, 0, 0, 1.0f);
 }
 
 // BatchNorm (training) + ReLU over Z[rows][C] -> A (mapped rows), statistics kept in `stats`, moving stats updated
+// stat_tiles > 0: the product that wrote Z left per-row-tile column sums in cx.stat_part ([stat_tiles][2][C * ntaps])
 void bn_relu_forward(const TrainCtx& cx, const float* Z, long rows, int C, const float* gamma, const float* beta,
                      float* stats, float* sums, float* mmean, float* mvar, float momentum, float* A, int ld, int co_off,
-                     RowMap rm) {
-    PP_LAUNCH("k_tr_colstats", k_tr_colstats, dim3(TR_NPART), dim3(256), 0, cx.stream, Z, rows, C, cx.part);
-    PP_LAUNCH("k_tr_bn_finalize", k_tr_bn_finalize, dim3((C + 15) / 16), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
-              C, (float)rows, (const float*)nullptr, momentum, 1, stats, mmean, mvar);
+                     RowMap rm, int stat_tiles = 0, int ntaps = 1) {
+    if (stat_tiles > 0) {
+        bn_finalize(cx, cx.stat_part, stat_tiles, C, (float)rows, nullptr, momentum, 1, stats, mmean, mvar, ntaps);
+    } else {
+        PP_LAUNCH("k_tr_colstats", k_tr_colstats, dim3(TR_NPART), dim3(256), 0, cx.stream, Z, rows, C, cx.part);
+        bn_finalize(cx, cx.part, TR_NPART, C, (float)rows, nullptr, momentum, 1, stats, mmean, mvar, 1);
+    }
     (void)sums;
     PP_LAUNCH("k_tr_bn_relu", k_tr_bn_relu, dim3(blocks_for(rows * (C / 4))), dim3(256), 0, cx.stream, Z, rows, C,
               (const float*)stats, gamma, beta, A, ld, co_off, rm);
@@ -827,8 +1151,8 @@ template <int CPL>
 void pfn_forward(const TrainCtx& cx, const PfnT& p, const Lookup& L) {
     PP_LAUNCH("k_tr_pfn_rows", k_tr_pfn_rows, dim3(1), dim3(64), 0, cx.stream, p.npillars, p.batch, p.T, cx.pfn_nrows);
     PP_LAUNCH("k_tr_pfn_lin", (k_tr_pfn_lin<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, cx.pfn_y, cx.part);
-    PP_LAUNCH("k_tr_bn_finalize", k_tr_bn_finalize, dim3((p.C + 15) / 16), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
-              p.C, 0.f, (const float*)cx.pfn_nrows, 0.01f, 0, cx.pfn_stats, L.s("pfn/bn/moving_mean"), L.s("pfn/bn/moving_variance"));
+    bn_finalize(cx, cx.part, TR_NPART, p.C, 0.f, cx.pfn_nrows, 0.01f, 0, cx.pfn_stats, L.s("pfn/bn/moving_mean"),
+                L.s("pfn/bn/moving_variance"), 1);
     PP_LAUNCH("k_tr_pfn_max", (k_tr_pfn_max<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, (const float*)cx.pfn_y,
               (const float*)cx.pfn_stats, L.p("pfn/bn/gamma"), L.p("pfn/bn/beta"), cx.pfn_feat, cx.pfn_arg);
 }
@@ -854,13 +1178,17 @@ size_t train_part_floats(const TrainShape& s) {
     size_t m = (size_t)2 * 512;
     m = std::max(m, (size_t)10 * s.C);
     for (const LayerDesc& L : s.layers) m = std::max(m, (size_t)9 * std::max(L.cin, L.cout));
-    return (size_t)TR_NPART * m;
+    return (size_t)TR_NPART_MAX * m;
 }
 
 int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainEntry>& layout, const float* params,
                float* grads, float* state, int batch, const LossParams& loss_in) {
     Lookup L{layout, params, grads, state};
     const int B = batch;
+    {   // partial rows of the persistent reductions: ~128 rows of the largest map per workgroup, one per CU at least
+        long want = ((long)B * s.ny * s.nx / 128 + 255) / 256 * 256;
+        g_tr_npart = (int)std::min<long>(TR_NPART_MAX, std::max<long>(256, want));
+    }
     if (s.C > 256 || s.C % 4 != 0 || s.FA > 10) return PP_ERR_UNSUPPORTED;
     for (const LayerDesc& l : s.layers)   // channel counts the reduction kernels are written for
         if (l.kind != LAYER_HEAD && (l.cin % 16 != 0 || l.cout < 32 || l.cout > 256 || (l.cout & (l.cout - 1)) != 0 ||
@@ -896,9 +1224,10 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
             PP_LAUNCH("k_tr_dw_fwd", k_tr_dw_fwd, dim3(blocks_for(rows * (l.cin / 4))), dim3(256), 0, cx.stream, cur,
                       L.p(pre + "/depthwise_kernel"), tb.D, B, l.in_h, l.in_w, l.out_h, l.out_w, l.cin, l.stride);
             tr_gemm(cx, tb.D, l.cin, 1, L.p(pre + "/pointwise_kernel"), l.cout, 1, tb.Z, l.cout, (int)rows, l.cout, l.cin,
-                    nullptr, 0, 1);
+                    nullptr, 0, 1, cx.stat_part);
             bn_relu_forward(cx, tb.Z, rows, l.cout, L.p(pre + "/bn/gamma"), L.p(pre + "/bn/beta"), tb.stats, tb.sums,
-                            L.s(pre + "/bn/moving_mean"), L.s(pre + "/bn/moving_variance"), 0.99f, tb.A, l.cout, 0, ident);
+                            L.s(pre + "/bn/moving_mean"), L.s(pre + "/bn/moving_variance"), 0.99f, tb.A, l.cout, 0, ident,
+                            g_last_stat_tiles, 1);
             cur = tb.A;
             ++li;
         } else if (l.kind == LAYER_DECONV) {
@@ -906,10 +1235,11 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
             const long m = (long)B * l.in_h * l.in_w;
             const int N = l.k * l.k * l.cout;
             // Zs[m][tap * cout + co] = X[m][:] . K[tap][co][:]   (Keras Conv2DTranspose kernel [k, k, Cout, Cin])
-            tr_gemm(cx, cur, l.cin, 1, L.p(pre + "/kernel"), 1, l.cin, tb.Z, N, (int)m, N, l.cin, nullptr, 0, 1);
+            tr_gemm(cx, cur, l.cin, 1, L.p(pre + "/kernel"), 1, l.cin, tb.Z, N, (int)m, N, l.cin, nullptr, 0, 1, cx.stat_part);
             const RowMap rm{l.k, l.in_h, l.in_w};
             bn_relu_forward(cx, tb.Z, m * l.k * l.k, l.cout, L.p(pre + "/bn/gamma"), L.p(pre + "/bn/beta"), tb.stats, tb.sums,
-                            L.s(pre + "/bn/moving_mean"), L.s(pre + "/bn/moving_variance"), 0.99f, cx.cat, s.CC, co_off, rm);
+                            L.s(pre + "/bn/moving_mean"), L.s(pre + "/bn/moving_variance"), 0.99f, cx.cat, s.CC, co_off, rm,
+                            g_last_stat_tiles, l.k * l.k);
             co_off += l.cout;
             ++bi; li = 0;
         }

@@ -383,11 +383,12 @@ class Engine:
                "num_positives": int(losses[6])}
         if want_grad:
             na = self.d.num_anchor_per_loc
-            nb = na * 7
+            nb, nc = na * 7, na * self.d.num_class      # head row: [box na*7 | cls na*num_class | dir na*2 | pad]
             out["head_grad"] = grad
             out["box_preds_grad"] = grad[:, :, :nb].reshape(batch, hh, hw, nb)
-            out["cls_preds_grad"] = grad[:, :, nb:nb + na].reshape(batch, hh, hw, na)
-            out["dir_cls_preds_grad"] = grad[:, :, nb + na:nb + 3 * na].reshape(batch, hh, hw, 2 * na)
+            out["cls_preds_grad"] = grad[:, :, nb:nb + nc].reshape(batch, hh, hw, nc)
+            if self.d.use_direction_classifier:
+                out["dir_cls_preds_grad"] = grad[:, :, nb + nc:nb + nc + 2 * na].reshape(batch, hh, hw, 2 * na)
         return out
 
     # ---- training step (f3) ----
@@ -438,6 +439,13 @@ class Engine:
         v = ctypes.c_int64(0)
         self._check(self._lib.pp_device_mem_free(self._h, ctypes.byref(v)), "pp_device_mem_free")
         return v.value
+
+    def device_copy_GBps(self, nbytes=1 << 30, reps=5):
+        """Device-to-device copy rate (read + written GB/s) measured on the engine's stream."""
+        g = ctypes.c_float(0)
+        self._check(self._lib.pp_device_copy_bench(self._h, ctypes.c_int64(int(nbytes)), int(reps), ctypes.byref(g)),
+                    "pp_device_copy_bench")
+        return float(g.value)
 
     def device_info(self):
         name = ctypes.create_string_buffer(256)

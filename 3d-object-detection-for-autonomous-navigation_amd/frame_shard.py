@@ -46,3 +46,63 @@ def gather_counts(count, dist=None, device=None):
     t[dist.get_rank()] = int(count)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(v) for v in t.tolist()]
+
+
+# ---- NUMA placement of a rank ("one process per GPU, NUMA-pinned") ----
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(pci_bus_id, sysfs="/sys"):
+    """NUMA node of the GPU at PCI address 'dddd:bb:dd.f' (sysfs numa_node), or None when the kernel does not say
+    (-1: single-node machine or no affinity information)."""
+    import os
+    path = os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id.lower(), "numa_node")
+    try:
+        node = int(open(path).read().strip())
+    except (OSError, ValueError):
+        return None
+    return node if node >= 0 else None
+
+
+def pin_to_gpu_numa_node(pci_bus_id, sysfs="/sys", apply=True):
+    """Restricts this process (and the threads it starts later) to the CPUs of the GPU's NUMA node, BEFORE the rank
+    allocates its page-locked staging pool: first-touch then places those pages on the node the GPU's host link
+    hangs off, and the feeding thread stays next to them.  Only CPUs the process may already use are kept (cgroup /
+    taskset limits are respected).  Returns a report dict; never raises -- a box without the sysfs files, or whose
+    node has none of our CPUs, is left as it is."""
+    import os
+    rep = {"pci_bus_id": pci_bus_id, "numa_node": None, "pinned": False}
+    try:
+        node = gpu_numa_node(pci_bus_id, sysfs)
+        rep["numa_node"] = node
+        if node is None:
+            rep["reason"] = "no NUMA affinity reported for the device"
+            return rep
+        cpus = _parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read())
+        allowed = os.sched_getaffinity(0)
+        keep = cpus & allowed
+        rep["node_cpus"] = len(cpus)
+        if not keep:
+            rep["reason"] = "none of the node's CPUs is in this process's affinity mask"
+            return rep
+        if apply and keep != allowed:
+            os.sched_setaffinity(0, keep)
+        rep["pinned"] = True
+        rep["cpus"] = len(keep)
+    except Exception as ex:   # noqa: BLE001 -- placement is an optimisation, never a failure
+        rep["reason"] = repr(ex)
+    return rep
+
+
+def device_pci_bus_id(local_rank):
+    """'dddd:bb:dd.f' of HIP device `local_rank` through torch's device properties (no kernel is launched)."""
+    import torch
+    p = torch.cuda.get_device_properties(local_rank)
+    return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"

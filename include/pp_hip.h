@@ -307,6 +307,11 @@ int pp_train_step(pp_handle h, const float* params_dev, float* grads_dev, float*
  * handle): steady-state steps must replay -- a regression check, not part of the reference's surface. */
 int pp_train_graph_stats(pp_handle h, int32_t* captures, int32_t* replays);
 
+/* Measurement helper: `reps` device-to-device copies of `bytes` on the handle's stream, timed with HIP events;
+ * *gbytes_per_s = read + written bytes per second (what an HBM-bound kernel can reach on this part, next to the
+ * spec constant the roofline fractions use). */
+int pp_device_copy_bench(pp_handle h, int64_t bytes, int32_t reps, float* gbytes_per_s);
+
 /* Device properties for reports: name (<=255 chars), CU count, bytes of HBM. */
 int pp_device_info(pp_handle h, char* name, int32_t name_capacity, int32_t* compute_units, int64_t* hbm_bytes);
 /* Bytes of HBM currently free on the handle's device (hipMemGetInfo): leak checks, sizing. */

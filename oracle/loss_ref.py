@@ -61,8 +61,12 @@ def loss_tensors(second_cfg, box, cls, dr, labels, reg_targets, anchors, dtype=t
 
     loc_red = loc_loss.sum() / B * s["loss"]["localization_weight"]
     cls_red = cls_loss.sum() / B * s["loss"]["classification_weight"]
-    cls_pos = ((labels_t > 0).to(dtype) * cls_loss.reshape(B, -1)).sum() / B
-    cls_neg = ((labels_t == 0).to(dtype) * cls_loss.reshape(B, -1)).sum() / B
+    if num_class == 1:     # _get_pos_neg_loss, model/voxelnet.py:48-61: by the anchor's label ...
+        cls_pos = ((labels_t > 0).to(dtype) * cls_loss.reshape(B, -1)).sum() / B
+        cls_neg = ((labels_t == 0).to(dtype) * cls_loss.reshape(B, -1)).sum() / B
+    else:                  # ... or column 0 against the other class columns
+        cls_pos = cls_loss[..., 1:].sum() / B
+        cls_neg = cls_loss[..., 0].sum() / B
     loss = loc_red + cls_red
     dir_red = torch.zeros((), dtype=dtype)
     if s["use_direction_classifier"]:
@@ -83,11 +87,12 @@ def training_loss(second_cfg, box_preds, cls_preds, dir_cls_preds, labels, reg_t
     reg_targets [B,A,7], anchors [A,7].  Returns (dict of python floats, dict of numpy gradients)."""
     box = torch.tensor(np.asarray(box_preds), dtype=dtype, requires_grad=True)
     cls = torch.tensor(np.asarray(cls_preds), dtype=dtype, requires_grad=True)
-    dr = torch.tensor(np.asarray(dir_cls_preds), dtype=dtype, requires_grad=True)
+    dr = torch.tensor(np.asarray(dir_cls_preds), dtype=dtype, requires_grad=True) if dir_cls_preds is not None else None
     t = loss_tensors(second_cfg, box, cls, dr, labels, reg_targets, anchors, dtype)
     t["loss"].backward()
     vals = {k: float(v.detach()) for k, v in t.items() if k != "num_positives"}
     vals["num_positives"] = int(t["num_positives"])
     grads = {"box_preds_grad": box.grad.numpy(), "cls_preds_grad": cls.grad.numpy(),
-             "dir_cls_preds_grad": dr.grad.numpy() if dr.grad is not None else np.zeros_like(np.asarray(dir_cls_preds))}
+             "dir_cls_preds_grad": (dr.grad.numpy() if dr is not None and dr.grad is not None
+                                    else (np.zeros_like(np.asarray(dir_cls_preds)) if dir_cls_preds is not None else None))}
     return vals, grads

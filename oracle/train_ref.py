@@ -75,11 +75,15 @@ def training_step(d, w, example, labels, reg_targets, anchors, num_threads=None,
     def head(name):
         return (Fn.conv2d(cat, t[name + "/kernel"].permute(3, 2, 0, 1), bias=t[name + "/bias"])).permute(0, 2, 3, 1)
 
-    box, cls, dr = head("rpn/conv_box"), head("rpn/conv_cls"), head("rpn/conv_dir_cls")
+    use_dir = bool(d.config["model"]["second"]["use_direction_classifier"])      # model/voxelnet.py:690
+    box, cls = head("rpn/conv_box"), head("rpn/conv_cls")
+    dr = head("rpn/conv_dir_cls") if use_dir else None
     lt = loss_ref.loss_tensors(d.config["model"]["second"], box, cls, dr, labels, reg_targets, anchors, dtype)
     lt["loss"].backward()
     vals = {k: float(vv.detach()) for k, vv in lt.items() if k != "num_positives"}
     vals["num_positives"] = int(lt["num_positives"])
     grads = {k: (tt.grad.numpy() if tt.grad is not None else np.zeros(tt.shape, np.float32)) for k, tt in t.items()}
-    preds = {"box_preds": box.detach().numpy(), "cls_preds": cls.detach().numpy(), "dir_cls_preds": dr.detach().numpy()}
+    preds = {"box_preds": box.detach().numpy(), "cls_preds": cls.detach().numpy()}
+    if dr is not None:
+        preds["dir_cls_preds"] = dr.detach().numpy()
     return vals, grads, stats, preds

@@ -490,6 +490,35 @@ def test_bench_two_rank_path_rehearsal(hip_lib):
     assert d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_one_rank_under_launcher_with_rccl(hip_lib):
+    """bench.py as the driver starts it for N > 1 -- under torch.distributed.run with the `nccl` backend (= RCCL) --
+    with ONE rank on this box's one GPU: the RCCL communicator is created before any engine exists, the device
+    barrier and the MAX / SUM all-reduces around the timed region run on the GPU, and the training leg's gradient
+    all-reduce goes through RCCL too.  (World size 1 moves no bytes between GPUs; what it covers is that the nccl
+    branch initialises and runs beside the engine's own non-blocking streams.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("PP_BENCH_DIST_BACKEND", None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29519", "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2",
+           "--batch", "8", "--no-latency-b1", "--no-cfgk", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = lines[0]
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config"]["collective_backend"].startswith("nccl"), d["config"]["collective_backend"]
+    tr = d["detail"]["train"]
+    assert "error" not in tr and tr["ms_per_step"] > 0 and np.isfinite(tr["last_loss"]), tr
+
+
 def _random_config(rng, B):
     """A small reference-schema config drawn at random: grid, first stride, z cells, channel widths, layer counts,
     point features, pillar capacity."""

@@ -480,14 +480,14 @@ def test_zero_copy_feed_buffer_lifetimes(pp, hip_lib):
 def test_folded_weights_outside_float16_range_fall_back_to_f32(pp, hip_lib):
     """The split-precision GEMM kernels carry a float32 operand as two float16 pieces, which needs |w| < 65504 for the
     BN-folded weights.  A layer whose folded weights do not fit must run on the float32 matrix instruction instead of
-    silently producing inf / NaN: deconv3 with BatchNorm gammas of 1e5 (its folded kernel reaches ~1e5), compensated
+    silently producing inf / NaN: deconv3 with BatchNorm gammas of 1e7 (its folded kernel reaches ~1e5-1e6), compensated
     in the head kernels' rows of that branch, so the outputs stay O(1) and comparable with the oracle."""
     B = 2
     cfg = pp.config.pedestrian_d435i_config(B)
     eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=8192)
     d = eng.d
     w = dict(pp.weights.init_weights(d, seed=41))
-    big = np.float32(1e5)
+    big = np.float32(1e7)
     w["rpn/deconv3/bn/gamma"] = w["rpn/deconv3/bn/gamma"] * big
     w["rpn/deconv3/bn/beta"] = w["rpn/deconv3/bn/beta"] * big
     c0 = 2 * 128                                                    # deconv3's slice of the 384 concat channels

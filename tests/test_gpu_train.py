@@ -51,6 +51,11 @@ def _variant(pp, name, B):
     elif name == "wide":
         s["rpn"].update(num_filters=[64, 128, 256], num_upsample_filters=[128, 128, 128])
         s["voxel_feature_extractor"]["num_filters"] = 128
+    elif name == "two-classes":          # the training branch is config-driven (model/voxelnet.py:74-155, :461-512)
+        s["num_class"] = 2
+    elif name == "three-classes-no-dir":
+        s["num_class"] = 3
+        s["use_direction_classifier"] = False
     elif name == "T50-F4-dist":
         s["voxel_generator"]["max_number_of_points_per_voxel"] = 50
         s["num_point_features"] = 4
@@ -59,7 +64,7 @@ def _variant(pp, name, B):
     return copy.deepcopy(cfg)
 
 
-@pytest.mark.parametrize("name", ["tiny", "deep", "wide", "T50-F4-dist"])
+@pytest.mark.parametrize("name", ["tiny", "deep", "wide", "T50-F4-dist", "two-classes", "three-classes-no-dir"])
 def test_gradients_match_autograd_small_grids(pp, hip_lib, name):
     """Every trainable tensor's gradient against torch autograd over the restated network (float32), on a 20x16
     grid where float32 round-off stays small: max |diff| <= 1e-4 of the tensor's largest gradient (measured ~5e-6).
@@ -75,6 +80,9 @@ def test_gradients_match_autograd_small_grids(pp, hip_lib, name):
         xyz = rng.uniform([0, -0.64, -3], [1.6, 0.64, 3], (n, 3))
         frames.append(np.concatenate([xyz, rng.uniform(0, 1, (n, F - 3))], axis=1).astype(np.float32))
     d, labels, reg = _problem(pp, cfg, frames, 11)
+    if d.num_class > 1:                                     # every class among the positives
+        lab_rng = np.random.default_rng(12)
+        labels[labels > 0] = lab_rng.integers(1, d.num_class + 1, int((labels > 0).sum()))
     w = pp.weights.init_weights(d, seed=21)
     tr = pp.Trainer(cfg, w, max_batch=B, max_points_per_frame=4096)
     out = tr.forward_backward(frames, labels, reg)
@@ -84,6 +92,8 @@ def test_gradients_match_autograd_small_grids(pp, hip_lib, name):
     vals, grads, stats, _ = train_ref.training_step(d, w, ex, labels, reg, ex[6][0])
     for k in ("loss", "loc_loss_reduced", "cls_loss_reduced", "dir_loss_reduced", "cls_pos_loss", "cls_neg_loss"):
         assert abs(out[k] - vals[k]) <= 1e-5 * max(1.0, abs(vals[k])), (k, out[k], vals[k])
+    if not d.use_direction_classifier:
+        assert out["dir_loss_reduced"] == 0.0 and "rpn/conv_dir_cls/kernel" not in tr.gradients()
     assert out["num_positives"] == vals["num_positives"]
     (wn, wmax), _ = _rel_errors(tr.gradients(), grads)
     print(f"{name}: {tr.params.numel()} trainable parameters, worst relative gradient error {wmax:.2e} ({wn})")

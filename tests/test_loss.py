@@ -126,6 +126,51 @@ def test_head_loss_kernel_matches_restatement(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["two_classes", "three_classes_no_direction"])
+def test_head_loss_kernel_config_branches(variant):
+    """The training branch of the reference is config-driven (model/voxelnet.py:74-155, :922-1049): several classes
+    (one sigmoid logit per class and anchor, one-hot targets without the background column) and a model without the
+    direction head -- the kernel against the restatement, values and gradients."""
+    import copy
+    B = 2
+    cfg = copy.deepcopy(pp.config.tiny_config(B))
+    s = cfg["model"]["second"]
+    if variant == "two_classes":
+        s["num_class"] = 2
+    else:
+        s["num_class"] = 3
+        s["use_direction_classifier"] = False
+    eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=4096)
+    d = eng.d
+    eng.load_weights(pp.weights.init_weights(d, seed=3))
+    rng = np.random.default_rng(31)
+    frames = [rng.uniform([0, -0.64, -3], [1.6, 0.64, 3], (n, 3)).astype(np.float32) for n in (700, 400)]
+    eng.detect(frames)
+    im = eng.intermediates()
+    anchors = pp.anchors.build_anchors(d)
+    labels = rng.choice([-1, 0, 0, 0, 0], size=(B, d.num_anchors)).astype(np.int32)
+    reg = np.zeros((B, d.num_anchors, 7), np.float32)
+    for b in range(B):
+        pos = rng.choice(d.num_anchors, 25, replace=False)
+        labels[b, pos] = rng.integers(1, s["num_class"] + 1, 25)          # every class appears
+        reg[b, pos] = rng.normal(0, 0.4, (25, 7)).astype(np.float32)
+    got = eng.head_loss(labels, reg)
+    vals, grads = loss_ref.training_loss(s, im["box_preds"], im["cls_preds"], im.get("dir_cls_preds"), labels, reg, anchors)
+    keys = ["loss", "loc_loss_reduced", "cls_loss_reduced", "cls_pos_loss", "cls_neg_loss"]
+    if s["use_direction_classifier"]:
+        keys.append("dir_loss_reduced")
+    for k in keys:
+        assert abs(got[k] - vals[k]) <= 2e-5 * max(1e-3, abs(vals[k])), (k, got[k], vals[k])
+    assert got["num_positives"] == vals["num_positives"] == 50
+    for k in ("box_preds_grad", "cls_preds_grad") + (("dir_cls_preds_grad",) if s["use_direction_classifier"] else ()):
+        np.testing.assert_allclose(got[k], grads[k], rtol=2e-4, atol=1e-8, err_msg=k)
+    na = d.num_anchor_per_loc
+    used = na * (7 + s["num_class"] + (2 if s["use_direction_classifier"] else 0))
+    assert not got["head_grad"][:, :, used:].any(), "columns past the heads get no gradient"
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_head_loss_argument_errors():
     eng = pp.Engine(pp.config.tiny_config(1), max_batch=1)
     eng.load_weights(pp.weights.init_weights(eng.d, seed=1))

@@ -64,3 +64,29 @@ def test_split_frames_strong_scaling(pp):
     assert s == [(0, 3), (3, 6), (6, 8), (8, 10)]
     with pytest.raises(ValueError):
         pp.frame_shard.rank_frames(3, 2, 4)
+
+
+def test_numa_pinning_from_sysfs(pp, tmp_path):
+    """pin_to_gpu_numa_node on a fake sysfs tree: the rank keeps the CPUs of the GPU's node that it may use, reports
+    what it did, and leaves the process alone when the kernel reports no affinity."""
+    allowed = sorted(os.sched_getaffinity(0))
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:0c:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    half = allowed[:max(1, len(allowed) // 2)]
+    (node / "cpulist").write_text(",".join(str(c) for c in half) + ",4090-4095\n")
+    rep = pp.frame_shard.pin_to_gpu_numa_node("0000:0C:00.0", sysfs=str(tmp_path), apply=False)
+    assert rep["numa_node"] == 1 and rep["pinned"] and rep["cpus"] == len(half) and rep["node_cpus"] == len(half) + 6
+    try:
+        rep = pp.frame_shard.pin_to_gpu_numa_node("0000:0c:00.0", sysfs=str(tmp_path), apply=True)
+        assert rep["pinned"] and sorted(os.sched_getaffinity(0)) == half
+    finally:
+        os.sched_setaffinity(0, allowed)
+    (dev / "numa_node").write_text("-1\n")
+    rep = pp.frame_shard.pin_to_gpu_numa_node("0000:0c:00.0", sysfs=str(tmp_path))
+    assert not rep["pinned"] and rep["numa_node"] is None
+    rep = pp.frame_shard.pin_to_gpu_numa_node("0000:ff:00.0", sysfs=str(tmp_path))     # unknown device
+    assert not rep["pinned"]
+    assert pp.frame_shard._parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}

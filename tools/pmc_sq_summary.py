@@ -49,12 +49,16 @@ for k, d in agg.items():
             if c in v:
                 v[key] = v[c] / v["SQ_WAVE_CYCLES"]
     out[k] = {c: (round(x, 4) if isinstance(x, float) and x < 10 else round(x)) for c, x in v.items()}
-try:
-    head = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-except Exception:
-    head = os.environ.get("PP_GIT_HEAD", "unknown")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha16  # noqa: E402
+head = os.environ.get("PP_GIT_HEAD", "")
+if not head:
+    try:
+        head = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        head = "unknown"
 json.dump({"note": __doc__.split("\n\n")[0] + "  Command: " + os.environ.get("PMC_CMD", "bench.py --plain --steps 4 --warmup 1 --inflight 1"),
-           "git_head": head, "kernels": out}, open(out_path, "w"), indent=1)
+           "git_head": head, "csrc_sha16": csrc_sha16(), "kernels": out}, open(out_path, "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("kernel_cycles", 0))[:14]:
     print(f"{k:28s} cyc {v.get('kernel_cycles', 0):>8} mfma {v.get('mfma_busy_frac', 0):.3f} w/simd {v.get('waves_per_simd', 0):.2f} "
           f"issue {v.get('issue_share', 0):.2f} stall {v.get('stall_share', 0):.2f} parked {v.get('parked_share', 0):.2f} "

@@ -34,7 +34,11 @@ for k in sorted(set(fetch) | set(write)):
     w_b = write.get(k, 0.0) * 1024
     out[short(k)] = {"fetch_bytes_per_launch": f_b, "write_bytes_per_launch": w_b,
                      "hbm_bytes_per_launch": f_b + w_b, "launches_sampled": nf.get(k, 0)}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha16  # noqa: E402
+json.dump({"git_head": os.environ.get("PP_GIT_HEAD", "unknown"), "csrc_sha16": csrc_sha16(),
+           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
                    "`bench.py --steps 4 --warmup 1 --no-cpu-baseline --inflight 1`; KB -> bytes, FETCH_SIZE x2 "
                    "(gfx950 correction for 16 B/lane reads)", "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:10]:
