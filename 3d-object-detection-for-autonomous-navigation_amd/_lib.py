@@ -104,7 +104,8 @@ _EXTRA = os.environ.get("PP_HIPCC_EXTRA", "").split()
 
 
 def _deps():
-    return [os.path.join(_CSRC, "pp_common.h"), os.path.join(_CSRC, "train.h"), _INCLUDE]
+    """Every header of csrc/ (and the C-ABI header): a change to any of them rebuilds every translation unit."""
+    return sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")) + [_INCLUDE]
 
 
 def needs_build():

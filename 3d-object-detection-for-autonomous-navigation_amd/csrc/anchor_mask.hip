@@ -10,7 +10,10 @@
 // from the voxeliser's cell -> pillar map.  Counts are kept in int32 (the
 // reference's float32 counts are exact integers).  HBM/L2-bound integer work:
 // 4*nz bytes read + 4 bytes written per cell, 16 B + 4 gathers + 1 B per anchor.
+#include <stdlib.h>
+
 #include "pp_common.h"
+#include "anchor_mask_dev.h"
 
 __global__ __launch_bounds__(256) void k_occ_rowscan(const int* __restrict__ cellmap, int rows, int nz, int ny,
                                                      int nx, int* __restrict__ integ) {
@@ -27,14 +30,9 @@ __global__ __launch_bounds__(256) void k_occ_rowscan(const int* __restrict__ cel
         int v = 0;
         if (x < nx)
             for (int z = 0; z < nz; ++z) v += (map[(size_t)z * plane + x] >= 0) ? 1 : 0;
-        int incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
+        const int incl = wave_inclusive_scan(v);
         if (x < nx) out[x] = carry + incl;
-        carry += __shfl(incl, 63);
+        carry += __builtin_amdgcn_readlane(incl, 63);
     }
 }
 
@@ -68,9 +66,29 @@ __global__ __launch_bounds__(256) void k_anchor_lookup(const int* __restrict__ i
     mask[(size_t)b * A + a] = ((float)area > threshold) ? 1 : 0;
 }
 
+// The same three steps for one frame in ONE workgroup when the BEV grid fits in LDS (the shipped 80 x 64 grid: 20 KB):
+// occupancy -> LDS, row scan (a wave per row), column scan (a thread per column), the anchors' four lookups out of LDS.
+// One launch instead of three: on a single frame (the reference's production mode) the three kernels were 12 us of
+// dependent launches for a few microseconds of work.
+__global__ __launch_bounds__(1024) void k_anchor_mask_frame(const int* __restrict__ cellmap, int nz, int ny, int nx,
+                                                            const int* __restrict__ cells, int64_t A, float threshold,
+                                                            uint8_t* __restrict__ mask) {
+    __shared__ int sI[AM_MAX_CELLS];
+    const int b = blockIdx.x;
+    anchor_mask_frame_block<1024>(cellmap + (size_t)b * nz * ny * nx, nz, ny, nx, cells, 0, A, threshold, mask + (size_t)b * A, sI);
+}
+
 void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, const int* cells, int64_t A,
                         float threshold, int* integ, uint8_t* mask, hipStream_t s) {
     if (batch <= 0) return;
+    static int fused = -1;      // PP_ANCHOR_MASK_FUSED=0: the three-kernel path everywhere (A/B measurements)
+    if (fused < 0) { const char* e = getenv("PP_ANCHOR_MASK_FUSED"); fused = (e && e[0] == '0') ? 0 : 1; }
+    // one workgroup per frame: the latency case (few frames); many frames keep the chip-wide kernels
+    if (fused && ny * (nx | 1) <= AM_MAX_CELLS && batch <= 8) {
+        PP_LAUNCH("k_anchor_mask_frame", k_anchor_mask_frame, dim3(batch), dim3(1024), 0, s, cellmap, nz, ny, nx, cells, A,
+                  threshold, mask);
+        return;
+    }
     const int rows = batch * ny;
     PP_LAUNCH("k_occ_rowscan", k_occ_rowscan, dim3((rows + 3) / 4), dim3(256), 0, s, cellmap, rows, nz, ny, nx, integ);
     PP_LAUNCH("k_colscan", k_colscan, dim3((batch * nx + 255) / 256), dim3(256), 0, s, integ, batch, ny, nx);

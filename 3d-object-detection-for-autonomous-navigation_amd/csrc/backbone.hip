@@ -1828,8 +1828,12 @@ __global__ __launch_bounds__(256, WPS) void k_deconv_u(GemmArgs a, int ntiles) {
 // (chunks ascending, three products per chunk smallest first), so the two kernels agree bit for bit.
 #ifdef PP_DECONV_ABLATE   // tuning build: pp_bench_layer's ablation bits switch phases of k_deconv_r off (wrong results)
 #define R_ABL(BIT) (a.dbg & (BIT))
+// bit 64: shader-clock stamps of workgroups 0..63 (wave 0): [0] start, [1] after the prologue, per unit u of the run
+// [2 + 8u] unit start, [3 + 8u] input tile in registers, [4 + 8u .. 7 + 8u] n-tiles done, [8 + 8u] head row stored
+#define R_STAMP(IDX) { if ((a.dbg & 64) && a.stamps && blockIdx.x < 64 && tid == 0 && (IDX) < 64) a.stamps[4096 * 8 + blockIdx.x * 64 + (IDX)] = clock64(); }
 #else
 #define R_ABL(BIT) false
+#define R_STAMP(IDX) {}
 #endif
 template <int CIN>
 __global__ __launch_bounds__(256, 2) void k_deconv_r(GemmArgs a, int nunits, int upw) {
@@ -1857,6 +1861,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_r(GemmArgs a, int nunits, int
     }
     const int u0 = wg * upw, u1 = min(u0 + upw, nunits);
     if (u0 >= u1) return;
+    R_STAMP(0)
     const int ntaps = a.k * a.k;
     const bool heads = a.head_mode != 0;
     const int hwpx = a.px_h * a.px_w, OW = a.px_w * a.k;
@@ -1900,6 +1905,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_r(GemmArgs a, int nunits, int
     R_STORE_W(0)
     R_LOAD_NEXT()                        // panel 1: written at step 0 of panel 0
     __syncthreads();
+    R_STAMP(1)
 
     bf16x8 xh[NCH], xm[NCH];             // the wave's 32 pixels x CIN channels, two float16 pieces
     int tile_cur = -1, opix0 = 0;
@@ -1918,6 +1924,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_r(GemmArgs a, int nunits, int
     }
 
     for (int u = u0; u < u1; ++u) {
+        R_STAMP(2 + 8 * (u - u0))
         if (tile != tile_cur) {          // uniform: fetch and split this tile's input once
             tile_cur = tile;
             const int pix = tile * 128 + wave * 32 + r32;
@@ -1940,6 +1947,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_r(GemmArgs a, int nunits, int
                 split_bf16x3(av, xh[c], xm[c], lo_);
             }
         }
+        R_STAMP(3 + 8 * (u - u0))
         const int ti = tap / a.k;
         const size_t orow = (size_t)(opix0 + ti * OW + (tap - ti * a.k));      // this lane's output pixel
         float* const hrow = a.head + orow * PP_HEAD_COLS + 4 * h;              // its columns 4h + {0..3, 8.., 16.., 24..}
@@ -2009,6 +2017,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_r(GemmArgs a, int nunits, int
                     for (int g = 0; g < 4; ++g)
                         *reinterpret_cast<float4*>(dst + nt * 32 + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
                 }
+                R_STAMP(4 + nt + 8 * (u - u0))
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -2025,10 +2034,12 @@ __global__ __launch_bounds__(256, 2) void k_deconv_r(GemmArgs a, int nunits, int
                 }
             }
         }
+        R_STAMP(8 + 8 * (u - u0))
         if (++tap == ntaps) { tap = 0; ++tile; }
     }
 #undef R_STORE_W
 #undef R_LOAD_NEXT
+#undef R_STAMP
 #undef R_ABL
 }
 

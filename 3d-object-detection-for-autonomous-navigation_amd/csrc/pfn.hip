@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "pp_common.h"
+#include "anchor_mask_dev.h"
 
 template <int N>
 struct FVec { float v[N]; };
@@ -247,11 +248,21 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int ncanvas = p.ny * p.nx;
+    if (p.am_mask != nullptr && blockIdx.x >= gridDim.x - AM_PFN_BLOCKS) {   // the frame's anchor mask rides in this launch
+        __shared__ int sI[AM_MAX_CELLS];
+        const int part = (int)blockIdx.x - ((int)gridDim.x - AM_PFN_BLOCKS);    // this workgroup's share of the anchors
+        const int64_t per = (p.am_A + AM_PFN_BLOCKS - 1) / AM_PFN_BLOCKS;
+        const int64_t a0 = part * per, a1 = (a0 + per < p.am_A) ? a0 + per : p.am_A;
+        anchor_mask_frame_block<256>(p.cellmap + (size_t)b * p.nz * ncanvas, p.nz, p.ny, p.nx, p.am_cells, a0, a1,
+                                     p.am_threshold, p.am_mask + (size_t)b * p.am_A, sI);
+        return;
+    }
     // a wave's PFN2_CW cells are spread over the map (cell = wave id + c * waves per frame), not contiguous:
     // points cluster (a person is a few dozen neighbouring cells with up to T points each), and a wave that owned
     // eight neighbouring crowded cells ran 30x longer than the average one -- the kernel's duration was its tail
     // (sparse canvas: contiguous cells instead -- on a mostly empty grid whole waves then have nothing to do)
-    const int NW = p.sparse ? 1 : gridDim.x * 4;      // cell stride: waves per frame (NW * PFN2_CW >= ncanvas) or 1
+    // cell stride: waves per frame (NW * PFN2_CW >= ncanvas; the anchor-mask workgroup does not count) or 1
+    const int NW = p.sparse ? 1 : ((int)gridDim.x - (p.am_mask != nullptr ? AM_PFN_BLOCKS : 0)) * 4;
     const int wid = p.sparse ? (blockIdx.x * 4 + wave) * PFN2_CW : blockIdx.x * 4 + wave;   // first cell
     if (wid >= ncanvas) return;
     const int ncells = min(PFN2_CW, (ncanvas - wid + NW - 1) / NW);
@@ -301,12 +312,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     }
 
     // ---- (1) stream layout: inclusive prefix of cnt over the slot lanes ----
-    int incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(incl, off);
-        if (lane >= off) incl += y;
-    }
+    const int incl = wave_inclusive_scan(cnt);
     const int excl = incl - cnt;
     const int tot = __builtin_amdgcn_readlane(incl, 63);
     if (p.sparse && tot == 0) return;                 // sparse canvas: nothing to write for cells without pillars
@@ -444,6 +450,12 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
 }
 
 // PP_PFN_KERNEL=1 selects the first-generation kernel for the fused path (A/B timing)
+static bool pfn_first_generation();
+// the extra anchor-mask workgroups ride in the second-generation CSR kernel only (dense canvas, grid fits the LDS image)
+bool pfn_can_carry_anchor_mask(const PfnParams& p, bool padded_source) {
+    return !padded_source && p.feat_out == nullptr && PFN2_CW * p.nz <= 64 && !pfn_first_generation() && !p.sparse &&
+           p.ny * (p.nx | 1) <= AM_MAX_CELLS && !p.with_distance;
+}
 static bool pfn_first_generation() {
     static int v = -1;
     if (v < 0) {
@@ -463,7 +475,7 @@ static void launch_pfn_t(const PfnParams& p, bool padded, hipStream_t s) {
     } else if (padded) {
         PP_LAUNCH("k_pfn_canvas", (k_pfn_canvas<CPL, F, true>), grid, dim3(256), 0, s, p);
     } else if (PFN2_CW * p.nz <= 64 && !pfn_first_generation()) {
-        dim3 grid2((ncanvas + 4 * PFN2_CW - 1) / (4 * PFN2_CW), p.batch);
+        dim3 grid2((ncanvas + 4 * PFN2_CW - 1) / (4 * PFN2_CW) + (p.am_mask != nullptr ? AM_PFN_BLOCKS : 0), p.batch);
         PP_LAUNCH("k_pfn_canvas2", (k_pfn_canvas2<CPL, F>), grid2, dim3(256), 0, s, p);
     } else {
         PP_LAUNCH("k_pfn_canvas", (k_pfn_canvas<CPL, F, false>), grid, dim3(256), 0, s, p);

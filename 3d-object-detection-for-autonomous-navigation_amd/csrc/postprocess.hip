@@ -151,12 +151,7 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         if (tid < 256) {
             const int lane_ = tid & 63, wv = tid >> 6;
             const int hv = s_hist[255 - tid];
-            int incl = hv;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int y = __shfl_up(incl, off);
-                if (lane_ >= off) incl += y;
-            }
+            const int incl = wave_inclusive_scan(hv);
             if (lane_ == 63) s_wsum[wv] = incl;
             s_cum[tid] = incl;   // within-wave inclusive sums; the wave offsets are added by thread 0 below
         }

@@ -136,6 +136,7 @@ struct pp_engine {
         int n_captures = 0, n_replays = 0;   // pp_train_graph_stats
     };
     TrainState* train = nullptr;
+    bool mask_in_pfn = false;      // the last run_pfn also computed the anchor mask (few frames)
     int f32_fallback_layers = 0;   // layers whose folded weights do not fit float16 pieces (pp_finalize_weights)
 
     int prof = 0;
@@ -420,7 +421,14 @@ const unsigned* sorted_idx(pp_engine* e) {
     return (voxel_sort_passes(e->cfg.max_voxels) % 2 == 0) ? e->d_idxA : e->d_idxB;
 }
 
-int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out) {
+// largest batch whose anchor masks ride in the PFN launch (PP_MASK_IN_PFN=0: never, =n: up to n frames)
+static int anchor_mask_in_pfn_max_batch() {
+    static int v = -1;
+    if (v < 0) { const char* s = getenv("PP_MASK_IN_PFN"); v = s ? atoi(s) : (1 << 30); }
+    return v;
+}
+
+int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out, bool with_mask = false) {
     PfnParams p;
     memset(&p, 0, sizeof(p));
     p.batch = batch; p.nz = e->nz; p.ny = e->ny; p.nx = e->nx; p.C = e->C; p.F = e->F; p.T = e->T;
@@ -436,6 +444,12 @@ int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out) {
     p.canvas = e->d_canvas; p.feat_out = feat_out;
     p.sparse = e->sparse_canvas ? 1 : 0;
     p.with_distance = e->with_dist ? 1 : 0;
+    e->mask_in_pfn = false;
+    if (with_mask && batch <= anchor_mask_in_pfn_max_batch() && pfn_can_carry_anchor_mask(p, padded)) {
+        // the anchor mask (needs the cell map only, read by the post-process only) rides in this launch
+        p.am_cells = e->d_cells; p.am_A = e->A; p.am_threshold = e->cfg.anchor_area_threshold; p.am_mask = e->d_mask;
+        e->mask_in_pfn = true;
+    }
     ProfScope ps(e, "k_pfn_canvas:pfn+scatter");
     int st = launch_pfn(p, padded, e->stream);
     if (st) return fail(e, st, "PFN: unsupported C=%d / F=%d", e->C, e->F);
@@ -1157,8 +1171,8 @@ static int graph_bucket(const pp_engine* e, int max_n) {
 static int enqueue_detect(pp_engine* e, int B, int max_n) {
     int st;
     if ((st = run_voxelize(e, B, max_n))) return st;
-    if ((st = run_pfn(e, B, false, nullptr))) return st;
-    if ((st = run_anchor_mask(e, B))) return st;
+    if ((st = run_pfn(e, B, false, nullptr, true))) return st;
+    if (!e->mask_in_pfn && (st = run_anchor_mask(e, B))) return st;
     if ((st = run_backbone(e, B))) return st;
     if ((st = run_post(e, B))) return st;
     HIPCHK(e, hipMemcpyAsync(e->h_dets, e->d_dets, (size_t)B * e->cfg.nms_post_max_size * sizeof(pp_detection), hipMemcpyDeviceToHost, e->stream));
@@ -1683,7 +1697,9 @@ int train_buffers(pp_engine* e) {
         }
         A1(dalloc(e, &cx.stat_part, need));
     }
-    cx.gemm_part_floats = 16l << 20;   // 64 MB of split-K partial tiles
+    // split-K partial tiles + the regions of the step's deferred reductions (every weight gradient keeps its
+    // partials until the end of the step): 64 MB at the reference's batch, 16 MB more per frame beyond 4
+    cx.gemm_part_floats = std::max<long>(16l << 20, (long)B * (4l << 20));
     A1(dalloc(e, &cx.gemm_part, (size_t)cx.gemm_part_floats));
     if (st == PP_OK) st = ensure_loss_buffers(e);
     if (st == PP_OK) t->buffers = true;

@@ -47,6 +47,20 @@ bool pp_prof_events(const char* name, hipEvent_t* start, hipEvent_t* stop);   //
             hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, STREAM, __VA_ARGS__);                            \
     } while (0)
 
+// inclusive prefix sum over the 64 lanes of a wave with DPP adds (row shifts inside the rows of 16, then the two row
+// broadcasts): six short VALU operations instead of six ds_bpermute round trips (__shfl_up) -- the scans of the
+// single-workgroup stages are dependent chains: their latency is what they cost
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+
 // ----- voxel grid geometry (float64, as the reference's index math) -----
 struct VoxGeom {
     double lo[3];   // range minimum x y z
@@ -137,7 +151,14 @@ struct PfnParams {
     int sparse;       // 1: only cells that hold a pillar are written (the first layer consults the cell map)
     int with_distance;  // 1: one more input feature, the point's Euclidean norm (w has F + 6 rows)
     float* feat_out;  // optional [P][C]
+    // few frames (the latency case): one extra workgroup per frame of the PFN launch computes the frame's anchor mask
+    // (it depends on the voxeliser's cell map only, and nothing before the post-process reads it): NULL = not fused
+    const int* am_cells;   // [A][4] static anchor cells
+    int64_t am_A;
+    float am_threshold;
+    uint8_t* am_mask;      // [batch][A]
 };
+bool pfn_can_carry_anchor_mask(const PfnParams& p, bool padded_source);   // would launch_pfn run the extra workgroups?
 int launch_pfn(const PfnParams& p, bool padded_source, hipStream_t s);  // returns 0 or PP_ERR_UNSUPPORTED
 
 void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, const int* cells, int64_t A,

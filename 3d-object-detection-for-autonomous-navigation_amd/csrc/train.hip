@@ -346,29 +346,142 @@ __global__ __launch_bounds__(256, 2) void k_tr_gemm2(TGemm2 a2) {
     }
 }
 
-// out[i] (+)= scale * sum_p part[p][i] in a fixed order (deterministic).  A workgroup owns 32 consecutive outputs
-// and cuts the partial rows into 8 interleaved slices (thread = (slice, output): a wave reads two 128-byte segments
-// per step, coalesced); slice s adds rows s, s + 8, ... in order, the 8 slice sums are added in order through LDS.
-__global__ __launch_bounds__(256) void k_tr_reduce(const float* __restrict__ part, int nparts, long n, long pstride,
-                                                   float* __restrict__ out, long ldo, int ncols, int accumulate, float scale) {
-    __shared__ float ssum[8][32];
-    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const long i = (long)blockIdx.x * 32 + o;
-    float s = 0.f;
-    if (i < n)
-        for (int p = sl; p < nparts; p += 8) s += part[(size_t)p * pstride + i];
-    ssum[sl][o] = s;
-    __syncthreads();
-    if (sl != 0 || i >= n) return;
-#pragma unroll
-    for (int k = 1; k < 8; ++k) s += ssum[k][o];
+// out[i] (+)= scale * sum_p part[p][i] in a fixed order (deterministic), two shapes:
+//   k_tr_reduce       many outputs (split-K partial tiles): a workgroup owns 64 consecutive outputs and cuts the
+//                     partial rows into 4 interleaved slices (thread = (slice, output): a wave reads 256 contiguous
+//                     bytes per row); a thread keeps 8 loads in flight and adds them in row order; the 4 slice sums
+//                     are added in order through LDS;
+//   k_tr_reduce_cols  few outputs, many partial rows (column sums of the persistent reductions): a whole wave per
+//                     output, lane l adds rows l, l + 64, ..., then a shuffle tree (the same tree every time).
+__device__ __forceinline__ void reduce_store(float s, long i, float* __restrict__ out, long ldo, int ncols, int accumulate,
+                                             float scale) {
     s *= scale;
     // optional re-striding of the output ([rows][ncols] with leading dimension ldo)
     float* q = (ncols > 0) ? out + (i / ncols) * ldo + (i % ncols) : out + i;
     *q = accumulate ? (*q + s) : s;
 }
 
-static unsigned reduce_blocks(long n) { return (unsigned)((n + 31) / 32); }
+__global__ __launch_bounds__(256) void k_tr_reduce(const float* __restrict__ part, int nparts, long n, long pstride,
+                                                   float* __restrict__ out, long ldo, int ncols, int accumulate, float scale) {
+    __shared__ float ssum[4][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + o;
+    float s = 0.f;
+    if (i < n) {
+        const float* q = part + i;
+        int p = sl;
+        for (; p + 28 < nparts; p += 32) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = q[(size_t)(p + 4 * k) * pstride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; p < nparts; p += 4) s += q[(size_t)p * pstride];
+    }
+    ssum[sl][o] = s;
+    __syncthreads();
+    if (sl != 0 || i >= n) return;
+    s = ((s + ssum[1][o]) + ssum[2][o]) + ssum[3][o];
+    reduce_store(s, i, out, ldo, ncols, accumulate, scale);
+}
+
+// dup0 / dup1: a second copy of the sums, outputs [0, dup_split) to dup0 and the rest to dup1 (the BatchNorm backward
+// sums ARE the beta / gamma gradients: written where the optimizer reads them, no copy nodes in the graph)
+__global__ __launch_bounds__(256) void k_tr_reduce_cols(const float* __restrict__ part, int nparts, long n, long pstride,
+                                                        float* __restrict__ out, long ldo, int ncols, int accumulate, float scale,
+                                                        float* __restrict__ dup0, float* __restrict__ dup1, int dup_split) {
+    const int l = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float s = 0.f;
+    if (i < n)
+        for (int p = l; p < nparts; p += 64) s += part[(size_t)p * pstride + i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (i >= n || l != 0) return;
+    reduce_store(s, i, out, ldo, ncols, accumulate, scale);
+    if (dup0 != nullptr) {
+        if (i < dup_split) dup0[i] = s * scale;
+        else dup1[i - dup_split] = s * scale;
+    }
+}
+
+// one reduction launch: the shape follows the number of outputs
+static void tr_reduce(hipStream_t st, const float* part, int nparts, long n, long pstride, float* out, long ldo, int ncols,
+                      int accumulate, float scale) {
+    if (n <= 4096 && nparts >= 64)
+        PP_LAUNCH("k_tr_reduce", k_tr_reduce_cols, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, part, nparts, n, pstride, out,
+                  ldo, ncols, accumulate, scale, (float*)nullptr, (float*)nullptr, 0);
+    else
+        PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, nparts, n, pstride, out, ldo,
+                  ncols, accumulate, scale);
+}
+
+
+// Deferred reductions.  The split-K partial tiles of the weight-gradient products and the partial rows of the depthwise
+// kernel gradients are needed by nobody before the optimizer: each gets a region of its own in the partial arena
+// (cx.gemm_part) and ONE launch at the end of the step adds them all -- at the reference's 2-frame batch the ~35
+// reduction launches they replaced were ~0.2 ms of a 2 ms step.
+struct ReduceJob {
+    const float* part; float* out;
+    long n, pstride, ldo;
+    int nparts, ncols, accumulate;
+    float scale;
+};
+#define TR_MULTI_MAX 40
+struct TMulti {
+    ReduceJob job[TR_MULTI_MAX];
+    int block_start[TR_MULTI_MAX + 1];
+    int njobs;
+};
+static std::vector<ReduceJob> g_jobs;     // this step's deferred reductions (train_step resets it)
+static long g_arena_used = 0;             // floats of cx.gemm_part handed out to them
+
+__global__ __launch_bounds__(256) void k_tr_reduce_multi(TMulti m) {
+    __shared__ float ssum[4][64];
+    int j = 0;
+    while (j + 1 < m.njobs && (int)blockIdx.x >= m.block_start[j + 1]) ++j;     // uniform
+    const ReduceJob& J = m.job[j];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i = (long)((int)blockIdx.x - m.block_start[j]) * 64 + o;
+    float s = 0.f;
+    if (i < J.n) {
+        const float* q = J.part + i;
+        int p = sl;
+        for (; p + 28 < J.nparts; p += 32) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = q[(size_t)(p + 4 * k) * J.pstride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; p < J.nparts; p += 4) s += q[(size_t)p * J.pstride];
+    }
+    ssum[sl][o] = s;
+    __syncthreads();
+    if (sl != 0 || i >= J.n) return;
+    s = ((s + ssum[1][o]) + ssum[2][o]) + ssum[3][o];
+    reduce_store(s, i, J.out, J.ldo, J.ncols, J.accumulate, J.scale);
+}
+
+static void flush_deferred(const TrainCtx& cx) {
+    size_t done = 0;
+    while (done < g_jobs.size()) {
+        TMulti m;
+        m.njobs = 0;
+        int blocks = 0;
+        while (done < g_jobs.size() && m.njobs < TR_MULTI_MAX) {
+            m.job[m.njobs] = g_jobs[done++];
+            m.block_start[m.njobs] = blocks;
+            blocks += (int)((m.job[m.njobs].n + 63) / 64);
+            ++m.njobs;
+        }
+        m.block_start[m.njobs] = blocks;
+        for (int k = m.njobs + 1; k <= TR_MULTI_MAX; ++k) m.block_start[k] = blocks;
+        PP_LAUNCH("k_tr_reduce_multi", k_tr_reduce_multi, dim3((unsigned)blocks), dim3(256), 0, cx.stream, m);
+    }
+    g_jobs.clear();
+}
 
 // PP_TRAIN_GEMM=f32 keeps every product on the float32 matrix instruction (k_tr_gemm)
 static bool train_split_gemm() {
@@ -388,13 +501,29 @@ static void launch_gemm2(const TGemm2& a2, bool akc, bool bkc, dim3 grid, hipStr
 // rows of the statistics partials a forward product leaves ([tiles][2][N]; 0: the split kernel did not run)
 static int g_last_stat_tiles = 0;
 
+// defer: a split-K product whose result only the optimizer reads (weight gradients) keeps its partial tiles in a
+// region of its own and is reduced by the step's one deferred-reduction launch
 static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
-                    long ldc, int M, int N, int K, const float* bias, int accumulate, int ksplit, float* stat_part = nullptr) {
+                    long ldc, int M, int N, int K, const float* bias, int accumulate, int ksplit, float* stat_part = nullptr,
+                    bool defer = false) {
     TGemm g;
     g.A = A; g.sam = sam; g.sak = sak; g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc;
-    g.M = M; g.N = N; g.K = K; g.bias = bias; g.accumulate = accumulate; g.Cpart = cx.gemm_part;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.accumulate = accumulate;
     if (ksplit < 1) ksplit = 1;
+    // partial tiles go to the free tail of the arena (behind the regions of this step's deferred reductions)
+    const long avail = cx.gemm_part_floats - g_arena_used;
+    while (ksplit > 1 && (long)ksplit * M * N > avail) --ksplit;
+    g.Cpart = cx.gemm_part + g_arena_used;
     g_last_stat_tiles = 0;
+    auto finish_split = [&](int ks) {
+        const long n = (long)M * N;
+        if (defer) {
+            g_jobs.push_back(ReduceJob{g.Cpart, C, n, n, ldc, ks, N, accumulate, 1.0f});
+            g_arena_used += ((long)ks * n + 63) / 64 * 64;
+        } else {
+            tr_reduce(cx.stream, (const float*)g.Cpart, ks, n, n, C, ldc, N, accumulate, 1.0f);
+        }
+    };
     // the split-precision kernel: unit stride on one axis of each operand, 16-byte aligned rows
     const bool akc = sak == 1, bkc = sbk == 1;
     const bool a_ok = akc ? (sam % 4 == 0) : (sam == 1 && sak % 4 == 0 && M % 4 == 0);
@@ -415,11 +544,7 @@ static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, cons
             if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
             launch_gemm2<1, 1>(a2, akc, bkc, grid, cx.stream);
         }
-        if (ksplit > 1) {
-            const long n = (long)M * N;
-            PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(n)), dim3(256), 0, cx.stream,
-                      (const float*)cx.gemm_part, ksplit, n, n, C, ldc, N, accumulate, 1.0f);
-        }
+        if (ksplit > 1) finish_split(ksplit);
         return;
     }
     int kper = ((K + ksplit - 1) / ksplit + 15) / 16 * 16;
@@ -427,11 +552,7 @@ static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, cons
     g.kper = kper;
     dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
     PP_LAUNCH("k_tr_gemm", k_tr_gemm, grid, dim3(256), 0, cx.stream, g);
-    if (ksplit > 1) {
-        const long n = (long)M * N;
-        PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(n)), dim3(256), 0, cx.stream,
-                  (const float*)cx.gemm_part, ksplit, n, n, C, ldc, N, accumulate, 1.0f);
-    }
+    if (ksplit > 1) finish_split(ksplit);
 }
 
 // weight gradients: K = rows (pixels); enough slices to fill the chip, bounded by the partial buffer
@@ -1104,9 +1225,11 @@ static void bn_finalize(const TrainCtx& cx, const float* part, int nparts, int C
                   n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps);
 }
 
-void col_reduce(const TrainCtx& cx, int C, float* sums) {   // TR_NPART partial rows of [2][C] -> sums[2][C]
-    PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(2 * C)), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
-              (long)2 * C, (long)2 * C, sums, 0L, 0, 0, 1.0f);
+// TR_NPART partial rows of [2][C] -> sums[2][C] (and, when given, row 0 -> dup0[C], row 1 -> dup1[C])
+void col_reduce(const TrainCtx& cx, int C, float* sums, float* dup0 = nullptr, float* dup1 = nullptr) {
+    const long n = (long)2 * C;
+    PP_LAUNCH("k_tr_reduce", k_tr_reduce_cols, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, cx.stream, (const float*)cx.part,
+              TR_NPART, n, n, sums, 0L, 0, 0, 1.0f, dup0, dup1, C);
 }
 
 // BatchNorm (training) + ReLU over Z[rows][C] -> A (mapped rows), statistics kept in `stats`, moving stats updated
@@ -1131,9 +1254,7 @@ void bn_relu_backward(const TrainCtx& cx, const float* dA, int ld, int co_off, R
                       float* dZ) {
     PP_LAUNCH("k_tr_bn_bwd_reduce", k_tr_bn_bwd_reduce, dim3(TR_NPART), dim3(256), 0, cx.stream, dA, ld, co_off, rm, Z, rows,
               C, stats, gamma, beta, cx.part);
-    col_reduce(cx, C, sums);
-    (void)hipMemcpyAsync(dbeta, sums, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, cx.stream);
-    (void)hipMemcpyAsync(dgamma, sums + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, cx.stream);
+    col_reduce(cx, C, sums, dbeta, dgamma);
     PP_LAUNCH("k_tr_bn_bwd_apply", k_tr_bn_bwd_apply, dim3(blocks_for(rows * C)), dim3(256), 0, cx.stream, dA, ld, co_off, rm,
               Z, rows, C, stats, gamma, beta, (const float*)sums, (float)rows, dZ);
 }
@@ -1161,14 +1282,12 @@ template <int CPL>
 void pfn_backward(const TrainCtx& cx, const PfnT& p, const Lookup& L, const float* dcanvas) {
     PP_LAUNCH("k_tr_pfn_bwd_reduce", (k_tr_pfn_bwd_reduce<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p,
               (const float*)cx.pfn_y, (const float*)cx.pfn_stats, (const int*)cx.pfn_arg, dcanvas, cx.part);
-    col_reduce(cx, p.C, cx.pfn_sums);
-    (void)hipMemcpyAsync(L.g("pfn/bn/beta"), cx.pfn_sums, (size_t)p.C * sizeof(float), hipMemcpyDeviceToDevice, cx.stream);
-    (void)hipMemcpyAsync(L.g("pfn/bn/gamma"), cx.pfn_sums + p.C, (size_t)p.C * sizeof(float), hipMemcpyDeviceToDevice, cx.stream);
+    col_reduce(cx, p.C, cx.pfn_sums, L.g("pfn/bn/beta"), L.g("pfn/bn/gamma"));
     PP_LAUNCH("k_tr_pfn_bwd_apply", (k_tr_pfn_bwd_apply<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, (const float*)cx.pfn_y,
               (const float*)cx.pfn_stats, L.p("pfn/bn/gamma"), (const int*)cx.pfn_arg, dcanvas, (const float*)cx.pfn_sums,
               (const float*)cx.pfn_nrows, cx.part);
     const long n = (long)p.FA * p.C;
-    PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(n)), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART, n, n,
+    tr_reduce(cx.stream, (const float*)cx.part, TR_NPART, n, n,
               L.g("pfn/dense/kernel"), 0L, 0, 0, 1.0f);
 }
 
@@ -1185,6 +1304,8 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                float* grads, float* state, int batch, const LossParams& loss_in) {
     Lookup L{layout, params, grads, state};
     const int B = batch;
+    g_jobs.clear();
+    g_arena_used = 0;
     {   // partial rows of the persistent reductions: ~128 rows of the largest map per workgroup, one per CU at least
         long want = ((long)B * s.ny * s.nx / 128 + 255) / 256 * 256;
         g_tr_npart = (int)std::min<long>(TR_NPART_MAX, std::max<long>(256, want));
@@ -1264,7 +1385,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
     // ---------------- backward ----------------
     // heads: dWh = cat^T . dhead, dbias = column sums, dcat = dhead . Wh^T
     tr_gemm(cx, cx.cat, 1, s.CC, cx.dhead, PP_HEAD_COLS, 1, cx.dhead_w, PP_HEAD_COLS, s.CC, PP_HEAD_COLS, (int)px, nullptr, 0,
-            wgrad_split(cx, s.CC, PP_HEAD_COLS, (int)px));
+            wgrad_split(cx, s.CC, PP_HEAD_COLS, (int)px));      // (reduced at once: k_tr_unpack_head_grads reads it next)
     PP_LAUNCH("k_tr_colstats", k_tr_colstats, dim3(TR_NPART), dim3(256), 0, cx.stream, (const float*)cx.dhead, px, PP_HEAD_COLS,
               cx.part);
     col_reduce(cx, PP_HEAD_COLS, cx.dhead_b);   // [0][c] = column sums (the [1][c] half is unused)
@@ -1302,7 +1423,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                          L.p(dpre + "/bn/beta"), db.sums, L.g(dpre + "/bn/gamma"), L.g(dpre + "/bn/beta"), cx.dZ);
         // dK[n][cin] = dZs^T . X     dX[m][cin] (+)= dZs . K
         tr_gemm(cx, cx.dZ, 1, N, Xd, d.cin, 1, L.g(dpre + "/kernel"), d.cin, N, d.cin, (int)m, nullptr, 0,
-                wgrad_split(cx, N, d.cin, (int)m));
+                wgrad_split(cx, N, d.cin, (int)m), nullptr, true);
         float* dAct = cx.lbuf[last].dA;
         tr_gemm(cx, cx.dZ, N, 1, L.p(dpre + "/kernel"), d.cin, 1, dAct, d.cin, (int)m, d.cin, N, nullptr,
                 (b + 1 < nblocks) ? 1 : 0, 1);
@@ -1316,15 +1437,22 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                              L.p(pre + "/bn/beta"), tb.sums, L.g(pre + "/bn/gamma"), L.g(pre + "/bn/beta"), cx.dZ);
             // dWp[cin][cout] = D^T . dZ      dD[rows][cin] = dZ . Wp^T
             tr_gemm(cx, tb.D, 1, l.cin, cx.dZ, l.cout, 1, L.g(pre + "/pointwise_kernel"), l.cout, l.cin, l.cout, (int)rows,
-                    nullptr, 0, wgrad_split(cx, l.cin, l.cout, (int)rows));
+                    nullptr, 0, wgrad_split(cx, l.cin, l.cout, (int)rows), nullptr, true);
             tr_gemm(cx, cx.dZ, l.cout, 1, L.p(pre + "/pointwise_kernel"), 1, l.cout, cx.dD, l.cin, (int)rows, l.cin, l.cout,
                     nullptr, 0, 1);
-            PP_LAUNCH("k_tr_dw_bwd_w", k_tr_dw_bwd_w, dim3(TR_NPART), dim3(256), 0, cx.stream, X, (const float*)cx.dD, cx.part, B,
-                      l.in_h, l.in_w, l.out_h, l.out_w, l.cin, l.stride);
-            {
+            {   // partial rows [TR_NPART][9][cin] in a region of their own, added by the step's deferred-reduction launch
                 const long n = (long)9 * l.cin;
-                PP_LAUNCH("k_tr_reduce", k_tr_reduce, dim3(reduce_blocks(n)), dim3(256), 0, cx.stream, (const float*)cx.part, TR_NPART,
-                          n, n, L.g(pre + "/depthwise_kernel"), 0L, 0, 0, 1.0f);
+                float* region = cx.part;
+                const bool room = g_arena_used + (long)TR_NPART * n <= cx.gemm_part_floats;
+                if (room) region = cx.gemm_part + g_arena_used;
+                PP_LAUNCH("k_tr_dw_bwd_w", k_tr_dw_bwd_w, dim3(TR_NPART), dim3(256), 0, cx.stream, X, (const float*)cx.dD, region, B,
+                          l.in_h, l.in_w, l.out_h, l.out_w, l.cin, l.stride);
+                if (room) {
+                    g_jobs.push_back(ReduceJob{region, L.g(pre + "/depthwise_kernel"), n, n, 0L, TR_NPART, 0, 0, 1.0f});
+                    g_arena_used += ((long)TR_NPART * n + 63) / 64 * 64;
+                } else {
+                    tr_reduce(cx.stream, (const float*)cx.part, TR_NPART, n, n, L.g(pre + "/depthwise_kernel"), 0L, 0, 0, 1.0f);
+                }
             }
             // gradient of this layer's input: the previous layer's dA, the previous block's output gradient, or the canvas
             float* dX = (i == 0) ? cx.dcanvas : cx.lbuf[i - 1 - ((i == first_of_block[b] && b > 0) ? 1 : 0)].dA;
@@ -1337,5 +1465,6 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
     if (cpl == 1) pfn_backward<1>(cx, p, L, cx.dcanvas);
     else if (cpl == 2) pfn_backward<2>(cx, p, L, cx.dcanvas);
     else pfn_backward<4>(cx, p, L, cx.dcanvas);
+    flush_deferred(cx);     // weight-gradient partial tiles + depthwise-gradient partial rows, one launch
     return PP_OK;
 }

@@ -93,12 +93,7 @@ __global__ __launch_bounds__(256) void k_cell_first(const float* __restrict__ pt
 // exclusive scan of one int per thread over a 1024-thread block
 __device__ __forceinline__ int block_excl_scan(int v, int* s_tmp, int& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int y = __shfl_up(x, off);
-        if (lane >= off) x += y;
-    }
+    const int x = wave_inclusive_scan(v);
     if (lane == 63) s_tmp[wave] = x;
     __syncthreads();
     int woff = 0, tot = 0;

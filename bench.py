@@ -124,6 +124,7 @@ def stage_bytes(d, batch, n_points, n_pillars):
         "k_occ_rowscan": batch * (4 * d.ny * d.nx * d.nz + 4 * d.ny * d.nx),
         "k_colscan": batch * (8 * d.ny * d.nx),
         "k_anchor_lookup": batch * (4 * d.ny * d.nx + d.num_anchors * 17),
+        "k_anchor_mask_frame": batch * (4 * d.ny * d.nx * d.nz + d.num_anchors * 17),   # the three in one (few frames)
         "k_sort_points": batch * (4 * n_points + 2 * 4 * F * n_points),
         "k_postprocess": batch * (d.num_anchors * 5),
     }
@@ -331,7 +332,7 @@ def roofline_of(sym, r):
     return base
 
 
-def cfgk_leg(pp, local_rank, steps=12):
+def cfgk_leg(pp, local_rank, steps=12, only_inflight=None):
     """BASELINE.json configs[2]: KITTI-shaped clouds (20k points, 0.16 m pillars, 496x432 BEV, Pedestrian+Cyclist
     as two classes), batch 32 on one GPU, same feeder (a different staged batch per step)."""
     B, N = 32, 20000
@@ -348,13 +349,19 @@ def cfgk_leg(pp, local_rank, steps=12):
     sync = lambda: None
     out = {"workload": f"cfg-K (432x496 BEV, 0.16 m pillars, T=100, C=64, strides [2,2,2], 2 classes), B={B} x {N} pts, "
                        "upload inside the step"}
-    for nfl in (2, 1):
+    for nfl in ((2, 1) if only_inflight is None else (only_inflight,)):
         f = Feeder(engines[:nfl], stagings)
         el = timed_run(f, steps, 3, sync)
         key = "" if nfl == 2 else "_inflight1"
         out["fps" + key] = B * steps / el
         out["ms_per_step" + key] = el / steps * 1e3
         out["mean_detections_per_frame"] = f.n_det / max(f.n_batches * B, 1)
+    if only_inflight is not None:     # profiling run (rocprofv3 wraps it): one regime, no per-launch event pass
+        for s in stagings:
+            s.close()
+        for e in engines:
+            e.close()
+        return out
     samples = kernel_pass(engines[:1], lambda: Feeder(engines[:1], stagings), 3)
     kernel_ms, launches, per_layer, dropped = summarise(samples, 3)
     n_pillars = float(engines[0].intermediates()["n_pillars"].mean())
@@ -364,6 +371,21 @@ def cfgk_leg(pp, local_rank, steps=12):
     out["mean_pillars_per_frame"] = n_pillars
     out["kernel_ms_per_step_inflight1"] = {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])}
     out["roofline"] = roofline_of(dom, roofs[dom])
+    out["roofline"]["traffic"] = None
+    try:      # HBM traffic per launch from the committed cfg-K counter passes, quoted only for the sources it ran on
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_cfgk.json")))
+        if files:
+            doc = json.load(open(files[-1]))
+            ent = doc["kernels"].get(dom)
+            src = {"file": os.path.basename(files[-1]), "git_head": doc.get("git_head"), "csrc_sha16": doc.get("csrc_sha16")}
+            if ent is not None and doc.get("csrc_sha16") == csrc_sha16():
+                out["roofline"]["traffic"] = ent.get("hbm_bytes_per_launch")
+            else:
+                src["stale"] = "kernel sources changed since the pass" if ent is not None else "kernel not in the pass"
+            out["roofline"]["traffic_source"] = src
+    except Exception as ex:
+        out["roofline"]["traffic_source"] = {"error": repr(ex)}
     out["layer_ms"] = {k: round(v[0], 4) for k, v in per_layer.items()}
     for s in stagings:
         s.close()
@@ -523,7 +545,8 @@ def main():
     if args.only is not None:
         def _sync():
             torch.cuda.synchronize()
-        leg = cfgk_leg(pp, local_rank, steps=max(12, min(args.steps, 60))) if args.only == "cfgk" else \
+        leg = cfgk_leg(pp, local_rank, steps=max(4, min(args.steps, 60)),
+                       only_inflight=(args.inflight if "--inflight" in sys.argv else None)) if args.only == "cfgk" else \
             train_leg(pp, local_rank, rank, n_gpus, dist, comm_dev, _sync, steps=max(20, min(args.steps, 100)),
                       batch=args.train_batch or 2)
         if rank == 0:
