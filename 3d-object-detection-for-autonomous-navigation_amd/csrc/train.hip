@@ -24,6 +24,7 @@
 // over ALL P * T rows of the reference's padded tensor: the zero rows contribute nothing to the sums but count
 // in N, and a padded row that wins the max receives the gradient (it only reaches beta / gamma / the statistics).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -533,12 +534,20 @@ static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, cons
         ksplit = (K + kper - 1) / kper;
         g.kper = kper;
         TGemm2 a2{g, (ksplit == 1) ? stat_part : nullptr};
-        // big tiles when they still fill the chip, small ones otherwise
+        // big tiles when they still fill the chip (two workgroups per CU), small ones otherwise; 64-column layers keep
+        // 128 rows per workgroup (two accumulator tiles per wave share every weight fragment)
         const long big = (long)((M + 127) / 128) * ((N + 127) / 128) * ksplit;
-        if (N >= 128 && big >= 2 * 256) {
+        const long tall = (long)((M + 127) / 128) * ((N + 63) / 64) * ksplit;
+        static int thr = -1;      // PP_TRAIN_TILE_THR: workgroups a launch must still have for the larger tile
+        if (thr < 0) { const char* e = getenv("PP_TRAIN_TILE_THR"); thr = e ? atoi(e) : 512; }   // (measured at B=32: 512 2.15 ms of products, 256 2.22, 128 2.32)
+        if (N >= 128 && big >= thr) {
             dim3 grid((N + 127) / 128, (M + 127) / 128, ksplit);
             if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
             launch_gemm2<2, 2>(a2, akc, bkc, grid, cx.stream);
+        } else if (tall >= thr) {
+            dim3 grid((N + 63) / 64, (M + 127) / 128, ksplit);
+            if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
+            launch_gemm2<2, 1>(a2, akc, bkc, grid, cx.stream);
         } else {
             dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
             if (a2.stat_part) g_last_stat_tiles = (int)grid.y;

@@ -70,6 +70,36 @@ class Staging:
             pass
 
 
+class PinnedArray:
+    """A page-locked host buffer (pp_host_alloc) viewed as a numpy array of the given shape / dtype: what a data
+    loader fills in place so that the host-to-device copy of a training batch's targets is one DMA, not a staged
+    pageable copy."""
+
+    def __init__(self, lib, shape, dtype):
+        self._lib = lib
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = ctypes.c_void_p()
+        st = lib.pp_host_alloc(ctypes.c_int64(max(n * dt.itemsize, 4)), ctypes.byref(p))
+        if st != 0:
+            raise RuntimeError(f"pp_host_alloc({n * dt.itemsize}) failed ({_STATUS.get(st, st)})")
+        self._p = p
+        raw = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(max(n * dt.itemsize, 4),))
+        self.array = raw[:n * dt.itemsize].view(dt).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self._lib.pp_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """config: reference-schema dict (or a config.Derived).  max_batch /
     max_points_per_frame size the device workspaces."""
@@ -410,12 +440,16 @@ class Engine:
         self._check(self._lib.pp_train_graph_stats(self._h, ctypes.byref(c), ctypes.byref(r)), "pp_train_graph_stats")
         return c.value, r.value
 
+    def pinned(self, shape, dtype):
+        """A page-locked numpy array (PinnedArray) for targets / frames the loader fills in place."""
+        return PinnedArray(self._lib, shape, dtype)
+
     def train_step(self, params_ptr, grads_ptr, state_ptr, labels, reg_targets):
         """Forward (training mode) + loss + backward on the resident frames (pp_train_step).  The three pointers
         are integer device addresses of the flat float32 buffers; returns the reference's loss scalars."""
         labels = _i32(np.asarray(labels))
         batch = labels.shape[0]
-        reg_targets = _f32(np.asarray(reg_targets).reshape(batch, self.d.num_anchors, 7))
+        reg_targets = _f32(np.asarray(reg_targets).reshape(batch, self.d.num_anchors, 7))   # (no copy when already so)
         if labels.shape != (batch, self.d.num_anchors):
             raise ValueError(f"labels must be [B, {self.d.num_anchors}]")
         losses = np.zeros(8, np.float32)

@@ -179,6 +179,13 @@ def test_optimizer_steps_reduce_the_loss_and_export_to_inference(pp, hip_lib):
     # (round 2 kept ONE graph keyed on the buffer and re-captured ~270 nodes on every optimizer step)
     captures, replays = tr.engine.train_graph_stats()
     assert captures <= 2 and replays == 12, (captures, replays)
+    # a batch staged in page-locked memory (three DMA transfers) gives the bits of the pageable path
+    a = tr.forward_backward(frames, labels, reg)
+    ga = tr.grads.cpu().numpy().copy()
+    st = tr.stage(frames, labels, reg)
+    b = tr.forward_backward(st)
+    assert a["loss"] == b["loss"] and np.array_equal(tr.grads.cpu().numpy(), ga)
+    st.close()
     # the trained tensors (and the updated moving statistics) load into an inference engine
     w = tr.weights()
     pp.weights.check_weights(d, w)
