@@ -248,9 +248,14 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int ncanvas = p.ny * p.nx;
-    if (p.am_mask != nullptr && blockIdx.x >= gridDim.x - AM_PFN_BLOCKS) {   // the frame's anchor mask rides in this launch
-        __shared__ int sI[AM_MAX_CELLS];
-        const int part = (int)blockIdx.x - ((int)gridDim.x - AM_PFN_BLOCKS);    // this workgroup's share of the anchors
+    // the frame's anchor mask rides in this launch: its workgroups come FIRST in dispatch order (they are a few serial
+    // phases long; at the end of the grid they were the launch's tail: +25 us at B = 64)
+    const int amb = (p.am_mask != nullptr) ? AM_PFN_BLOCKS : 0;
+    if ((int)blockIdx.x < amb) {
+        // the LDS image is DYNAMIC shared memory, sized by the launcher (zero without the mask): a static array would
+        // cap every PFN workgroup of every launch at 160 KB / 32 KB = 5 per CU (measured: B = 64 73 -> 90 us)
+        extern __shared__ int sI[];
+        const int part = (int)blockIdx.x;                                       // this workgroup's share of the anchors
         const int64_t per = (p.am_A + AM_PFN_BLOCKS - 1) / AM_PFN_BLOCKS;
         const int64_t a0 = part * per, a1 = (a0 + per < p.am_A) ? a0 + per : p.am_A;
         anchor_mask_frame_block<256>(p.cellmap + (size_t)b * p.nz * ncanvas, p.nz, p.ny, p.nx, p.am_cells, a0, a1,
@@ -262,8 +267,9 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     // eight neighbouring crowded cells ran 30x longer than the average one -- the kernel's duration was its tail
     // (sparse canvas: contiguous cells instead -- on a mostly empty grid whole waves then have nothing to do)
     // cell stride: waves per frame (NW * PFN2_CW >= ncanvas; the anchor-mask workgroup does not count) or 1
-    const int NW = p.sparse ? 1 : ((int)gridDim.x - (p.am_mask != nullptr ? AM_PFN_BLOCKS : 0)) * 4;
-    const int wid = p.sparse ? (blockIdx.x * 4 + wave) * PFN2_CW : blockIdx.x * 4 + wave;   // first cell
+    const int bx = (int)blockIdx.x - amb;
+    const int NW = p.sparse ? 1 : ((int)gridDim.x - amb) * 4;
+    const int wid = p.sparse ? (bx * 4 + wave) * PFN2_CW : bx * 4 + wave;   // first cell
     if (wid >= ncanvas) return;
     const int ncells = min(PFN2_CW, (ncanvas - wid + NW - 1) / NW);
     const int nz = p.nz;
@@ -476,7 +482,8 @@ static void launch_pfn_t(const PfnParams& p, bool padded, hipStream_t s) {
         PP_LAUNCH("k_pfn_canvas", (k_pfn_canvas<CPL, F, true>), grid, dim3(256), 0, s, p);
     } else if (PFN2_CW * p.nz <= 64 && !pfn_first_generation()) {
         dim3 grid2((ncanvas + 4 * PFN2_CW - 1) / (4 * PFN2_CW) + (p.am_mask != nullptr ? AM_PFN_BLOCKS : 0), p.batch);
-        PP_LAUNCH("k_pfn_canvas2", (k_pfn_canvas2<CPL, F>), grid2, dim3(256), 0, s, p);
+        const size_t lds = (p.am_mask != nullptr) ? (size_t)p.ny * (p.nx | 1) * sizeof(int) : 0;
+        PP_LAUNCH("k_pfn_canvas2", (k_pfn_canvas2<CPL, F>), grid2, dim3(256), lds, s, p);
     } else {
         PP_LAUNCH("k_pfn_canvas", (k_pfn_canvas<CPL, F, false>), grid, dim3(256), 0, s, p);
     }

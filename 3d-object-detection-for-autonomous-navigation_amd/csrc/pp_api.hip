@@ -421,10 +421,13 @@ const unsigned* sorted_idx(pp_engine* e) {
     return (voxel_sort_passes(e->cfg.max_voxels) % 2 == 0) ? e->d_idxA : e->d_idxB;
 }
 
-// largest batch whose anchor masks ride in the PFN launch (PP_MASK_IN_PFN=0: never, =n: up to n frames)
+// largest batch whose anchor masks ride in the PFN launch (PP_MASK_IN_PFN=0: never, =n: up to n frames).  Few frames
+// only: the 32 KB LDS image the extra workgroups declare caps EVERY workgroup of the launch at 5 per CU, and a full
+// chip of PFN workgroups lives on occupancy (B = 64: 73 -> 99 us with the masks inside, against 14 us for the three
+// mask kernels by themselves); on one frame the launch is 14.7 us instead of 12.2 + 8.8.
 static int anchor_mask_in_pfn_max_batch() {
     static int v = -1;
-    if (v < 0) { const char* s = getenv("PP_MASK_IN_PFN"); v = s ? atoi(s) : (1 << 30); }
+    if (v < 0) { const char* s = getenv("PP_MASK_IN_PFN"); v = s ? atoi(s) : 8; }
     return v;
 }
 
