@@ -576,6 +576,24 @@ static int wgrad_split(const TrainCtx& cx, int M, int N, int K) {
 // ------------------------------------------------------------------------------------------------------------
 // element kernels
 // ------------------------------------------------------------------------------------------------------------
+// Index arithmetic of the element kernels in 32 bits: a division by a run-time divisor is a shift when the divisor is
+// a power of two (channel counts, taps) and one 32-bit unsigned division otherwise (map widths).  The first versions
+// of these kernels did four 64-bit divisions per thread -- several hundred instructions of address arithmetic around
+// twenty of work: they were bound by vector issue, not by memory.
+struct Div32 {
+    unsigned d;
+    int shift;      // log2(d) when d is a power of two, else -1
+};
+static Div32 make_div(unsigned d) {
+    Div32 r{d, -1};
+    if (d && (d & (d - 1)) == 0) { r.shift = 0; while ((1u << r.shift) < d) ++r.shift; }
+    return r;
+}
+__device__ __forceinline__ void divmod32(unsigned n, const Div32& dv, unsigned& q, unsigned& r) {
+    if (dv.shift >= 0) { q = n >> dv.shift; r = n & (dv.d - 1u); }
+    else { q = n / dv.d; r = n - q * dv.d; }
+}
+
 __global__ __launch_bounds__(256) void k_tr_fill(float* p, long n, float v) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
@@ -584,66 +602,64 @@ __global__ __launch_bounds__(256) void k_tr_fill(float* p, long n, float v) {
 // depthwise 3x3, symmetric padding 1, stride S (ZeroPadding2D(1) + 'valid' == 'same' for stride 1):
 // D[b,y,x,c] = sum_t X[b, y*S-1+dy, x*S-1+dx, c] * w[t][c]
 __global__ __launch_bounds__(256) void k_tr_dw_fwd(const float* __restrict__ X, const float* __restrict__ w,
-                                                   float* __restrict__ D, int B, int ih, int iw, int oh, int ow, int C, int S) {
-    const int c4n = C / 4;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)B * oh * ow * c4n;
+                                                   float* __restrict__ D, unsigned total, int ih, int iw, Div32 doh, Div32 dow,
+                                                   Div32 dc4, int C, int S) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;      // (pixel, channel quad); total < 2^32 (launcher)
     if (i >= total) return;
-    const int c = (int)(i % c4n) * 4;
-    long p = i / c4n;
-    const int x = (int)(p % ow); p /= ow;
-    const int y = (int)(p % oh);
-    const int b = (int)(p / oh);
+    unsigned p, cq, x, y, b;
+    divmod32(i, dc4, p, cq);
+    divmod32(p, dow, p, x);
+    divmod32(p, doh, b, y);
+    const int c = (int)cq * 4;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
-        const int yy = y * S - 1 + dy;
+        const int yy = (int)y * S - 1 + dy;
         if ((unsigned)yy >= (unsigned)ih) continue;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int xx = x * S - 1 + dx;
+            const int xx = (int)x * S - 1 + dx;
             if ((unsigned)xx >= (unsigned)iw) continue;
             const float4 v = *reinterpret_cast<const float4*>(X + (((size_t)b * ih + yy) * iw + xx) * C + c);
             const float4 k = *reinterpret_cast<const float4*>(w + (size_t)(dy * 3 + dx) * C + c);
             o.x = fmaf(v.x, k.x, o.x); o.y = fmaf(v.y, k.y, o.y); o.z = fmaf(v.z, k.z, o.z); o.w = fmaf(v.w, k.w, o.w);
         }
     }
-    *reinterpret_cast<float4*>(D + (size_t)(i / c4n) * C + c) = o;
+    *reinterpret_cast<float4*>(D + (size_t)i * 4) = o;        // D is [pixel][C]: element (pixel, quad) is at i * 4
 }
+
 
 // gradient of the depthwise convolution with respect to its input:
 // dX[b,yy,xx,c] (+)= sum over taps with (yy+1-dy) % S == 0 ... of dD[b,(yy+1-dy)/S,(xx+1-dx)/S,c] * w[t][c]
 __global__ __launch_bounds__(256) void k_tr_dw_bwd_in(const float* __restrict__ dD, const float* __restrict__ w,
-                                                      float* __restrict__ dX, int B, int ih, int iw, int oh, int ow, int C,
-                                                      int S, int accumulate) {
-    const int c4n = C / 4;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)B * ih * iw * c4n;
+                                                      float* __restrict__ dX, unsigned total, Div32 dih, Div32 diw, int oh,
+                                                      int ow, Div32 dc4, int C, int S, int accumulate) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;      // (input pixel, channel quad)
     if (i >= total) return;
-    const int c = (int)(i % c4n) * 4;
-    long p = i / c4n;
-    const int xx = (int)(p % iw); p /= iw;
-    const int yy = (int)(p % ih);
-    const int b = (int)(p / ih);
+    unsigned p, cq, uxx, uyy, b;
+    divmod32(i, dc4, p, cq);
+    divmod32(p, diw, p, uxx);
+    divmod32(p, dih, b, uyy);
+    const int c = (int)cq * 4, xx = (int)uxx, yy = (int)uyy;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         const int ty = yy + 1 - dy;
-        if (ty < 0 || ty % S != 0) continue;
-        const int y = ty / S;
+        if (ty < 0 || (S == 2 && (ty & 1))) continue;        // S is 1 or 2 (train_step checks)
+        const int y = (S == 2) ? (ty >> 1) : ty;
         if (y >= oh) continue;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int tx = xx + 1 - dx;
-            if (tx < 0 || tx % S != 0) continue;
-            const int x = tx / S;
+            if (tx < 0 || (S == 2 && (tx & 1))) continue;
+            const int x = (S == 2) ? (tx >> 1) : tx;
             if (x >= ow) continue;
             const float4 v = *reinterpret_cast<const float4*>(dD + (((size_t)b * oh + y) * ow + x) * C + c);
             const float4 k = *reinterpret_cast<const float4*>(w + (size_t)(dy * 3 + dx) * C + c);
             o.x = fmaf(v.x, k.x, o.x); o.y = fmaf(v.y, k.y, o.y); o.z = fmaf(v.z, k.z, o.z); o.w = fmaf(v.w, k.w, o.w);
         }
     }
-    float4* dst = reinterpret_cast<float4*>(dX + (size_t)(i / c4n) * C + c);
+    float4* dst = reinterpret_cast<float4*>(dX + (size_t)i * 4);
     if (accumulate) { const float4 q = *dst; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
     *dst = o;
 }
@@ -665,10 +681,16 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd_w(const float* __restrict__ X
     float4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (b, y, x) of the thread's first pixel by division once, then advanced by nps pixels per iteration
+    int x = 0, y = 0, b = 0;
+    if (p0 + ps < p1) {
+        const unsigned up = (unsigned)(p0 + ps);             // pixel counts < 2^31 (launcher)
+        const unsigned qy = up / (unsigned)ow;
+        x = (int)(up - qy * (unsigned)ow);
+        b = (int)(qy / (unsigned)oh);
+        y = (int)(qy - (unsigned)b * (unsigned)oh);
+    }
     for (long p = p0 + ps; p < p1; p += nps) {
-        const int x = (int)(p % ow);
-        const int y = (int)((p / ow) % oh);
-        const int b = (int)(p / ((long)ow * oh));
         const float4 g = *reinterpret_cast<const float4*>(dD + (size_t)p * C + 4 * q);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
@@ -683,6 +705,8 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd_w(const float* __restrict__ X
                 }
             }
         }
+        x += nps;
+        while (x >= ow) { x -= ow; if (++y == oh) { y = 0; ++b; } }
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t) sred[t * 256 + tid] = acc[t];
@@ -768,26 +792,28 @@ __global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict_
 struct RowMap { int k, in_h, in_w; };
 __device__ __forceinline__ long map_row(const RowMap& m, long r) {
     if (m.k <= 1) return r;
-    const int kk = m.k * m.k;
-    const int tap = (int)(r % kk);
-    long p = r / kk;
-    const int x = (int)(p % m.in_w); p /= m.in_w;
-    const int y = (int)(p % m.in_h);
-    const long b = p / m.in_h;
-    const int ti = tap / m.k, tj = tap - ti * m.k;
-    return ((b * m.in_h * m.k + (long)y * m.k + ti) * ((long)m.in_w * m.k)) + (long)x * m.k + tj;
+    // rows < 2^31 (launcher): 32-bit arithmetic; kernel == stride k is 1, 2 or 4: the tap split is a shift
+    const unsigned kk = (unsigned)(m.k * m.k), ur = (unsigned)r;
+    unsigned p, tapr;
+    if (m.k == 2) { p = ur >> 2; tapr = ur & 3u; }
+    else if (m.k == 4) { p = ur >> 4; tapr = ur & 15u; }
+    else { p = ur / kk; tapr = ur - p * kk; }
+    const unsigned q = p / (unsigned)m.in_w, x = p - q * (unsigned)m.in_w;
+    const unsigned b = q / (unsigned)m.in_h, y = q - b * (unsigned)m.in_h;
+    const unsigned ti = tapr / (unsigned)m.k, tj = tapr - ti * (unsigned)m.k;
+    return ((long)(b * m.in_h * m.k + y * m.k + ti) * ((long)m.in_w * m.k)) + (long)(x * m.k + tj);
 }
 
 // A[map(r)][co_off + c] = relu((Z[r][c] - mean) * inv * gamma + beta)
 __global__ __launch_bounds__(256) void k_tr_bn_relu(const float* __restrict__ Z, long rows, int C, const float* __restrict__ stats,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float* __restrict__ A, int ld, int co_off, RowMap rm) {
-    const int c4n = C / 4;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * c4n) return;
-    const int c = (int)(i % c4n) * 4;
-    const long r = i / c4n;
-    const float4 z = *reinterpret_cast<const float4*>(Z + (size_t)r * C + c);
+    const unsigned c4n = (unsigned)C >> 2;                   // C is a power of two here (train_step checks): mask / shift
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;      // rows * C / 4 < 2^32 (launcher)
+    if ((long)i >= rows * (long)c4n) return;
+    const int c = (int)(i & (c4n - 1u)) * 4;
+    const long r = (long)(i / c4n);
+    const float4 z = *reinterpret_cast<const float4*>(Z + (size_t)i * 4);
     const float zz[4] = {z.x, z.y, z.z, z.w};
     float o[4];
 #pragma unroll
@@ -850,15 +876,24 @@ __global__ __launch_bounds__(256) void k_tr_bn_bwd_apply(const float* __restrict
                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ sums,
                                                          float n_rows, float* __restrict__ dZ) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * C) return;
-    const int c = (int)(i % C);
-    const long r = i / C;
-    const float mean = stats[2 * c], inv = stats[2 * c + 1], ga = gamma[c];
-    const float zh = (Z[i] - mean) * inv;
-    const float act = zh * ga + beta[c];
-    const float g = (act > 0.f) ? dA[(size_t)map_row(rm, r) * ld + co_off + c] : 0.f;
-    dZ[i] = ga * inv * (g - sums[c] / n_rows - zh * (sums[C + c] / n_rows));
+    const unsigned c4n = (unsigned)C >> 2;                   // C is a power of two (train_step checks)
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;      // (row, channel quad)
+    if ((long)i >= rows * (long)c4n) return;
+    const int c = (int)(i & (c4n - 1u)) * 4;
+    const long r = (long)(i / c4n);
+    const float4 z4 = *reinterpret_cast<const float4*>(Z + (size_t)i * 4);
+    const float4 d4 = *reinterpret_cast<const float4*>(dA + (size_t)map_row(rm, r) * ld + co_off + c);
+    const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float mean = stats[2 * (c + j)], inv = stats[2 * (c + j) + 1], ga = gamma[c + j];
+        const float zh = (zz[j] - mean) * inv;
+        const float act = zh * ga + beta[c + j];
+        const float g = (act > 0.f) ? dd[j] : 0.f;
+        o[j] = ga * inv * (g - sums[c + j] / n_rows - zh * (sums[C + c + j] / n_rows));
+    }
+    *reinterpret_cast<float4*>(dZ + (size_t)i * 4) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1264,7 +1299,7 @@ void bn_relu_backward(const TrainCtx& cx, const float* dA, int ld, int co_off, R
     PP_LAUNCH("k_tr_bn_bwd_reduce", k_tr_bn_bwd_reduce, dim3(TR_NPART), dim3(256), 0, cx.stream, dA, ld, co_off, rm, Z, rows,
               C, stats, gamma, beta, cx.part);
     col_reduce(cx, C, sums, dbeta, dgamma);
-    PP_LAUNCH("k_tr_bn_bwd_apply", k_tr_bn_bwd_apply, dim3(blocks_for(rows * C)), dim3(256), 0, cx.stream, dA, ld, co_off, rm,
+    PP_LAUNCH("k_tr_bn_bwd_apply", k_tr_bn_bwd_apply, dim3(blocks_for(rows * (C / 4))), dim3(256), 0, cx.stream, dA, ld, co_off, rm,
               Z, rows, C, stats, gamma, beta, (const float*)sums, (float)rows, dZ);
 }
 
@@ -1352,7 +1387,8 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
             const std::string pre = "rpn/block" + std::to_string(bi + 1) + "/" + std::to_string(li);
             const long rows = (long)B * l.out_h * l.out_w;
             PP_LAUNCH("k_tr_dw_fwd", k_tr_dw_fwd, dim3(blocks_for(rows * (l.cin / 4))), dim3(256), 0, cx.stream, cur,
-                      L.p(pre + "/depthwise_kernel"), tb.D, B, l.in_h, l.in_w, l.out_h, l.out_w, l.cin, l.stride);
+                      L.p(pre + "/depthwise_kernel"), tb.D, (unsigned)(rows * (l.cin / 4)), l.in_h, l.in_w,
+                      make_div((unsigned)l.out_h), make_div((unsigned)l.out_w), make_div((unsigned)(l.cin / 4)), l.cin, l.stride);
             tr_gemm(cx, tb.D, l.cin, 1, L.p(pre + "/pointwise_kernel"), l.cout, 1, tb.Z, l.cout, (int)rows, l.cout, l.cin,
                     nullptr, 0, 1, cx.stat_part);
             bn_relu_forward(cx, tb.Z, rows, l.cout, L.p(pre + "/bn/gamma"), L.p(pre + "/bn/beta"), tb.stats, tb.sums,
@@ -1466,8 +1502,9 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
             // gradient of this layer's input: the previous layer's dA, the previous block's output gradient, or the canvas
             float* dX = (i == 0) ? cx.dcanvas : cx.lbuf[i - 1 - ((i == first_of_block[b] && b > 0) ? 1 : 0)].dA;
             PP_LAUNCH("k_tr_dw_bwd_in", k_tr_dw_bwd_in, dim3(blocks_for((long)B * l.in_h * l.in_w * (l.cin / 4))), dim3(256), 0,
-                      cx.stream, (const float*)cx.dD, L.p(pre + "/depthwise_kernel"), dX, B, l.in_h, l.in_w, l.out_h, l.out_w,
-                      l.cin, l.stride, 0);
+                      cx.stream, (const float*)cx.dD, L.p(pre + "/depthwise_kernel"), dX,
+                      (unsigned)((long)B * l.in_h * l.in_w * (l.cin / 4)), make_div((unsigned)l.in_h), make_div((unsigned)l.in_w),
+                      l.out_h, l.out_w, make_div((unsigned)(l.cin / 4)), l.cin, l.stride, 0);
         }
     }
     // canvas -> pillar features -> PFN

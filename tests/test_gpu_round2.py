@@ -34,7 +34,7 @@ def _assert_dets(pp_dicts, ref_dicts, labels=False):
 # ------------------------------------------------------------------ the benchmarked shape, against the oracle
 def test_bench_batch_b64_matches_oracle_per_frame(pp, hip_lib):
     """cfg-A at B=64 is the only shape that runs the kernel instantiations bench.py times
-    (k_sep_u<128,1,2,1,0>, k_sep_u<64,1,3,1,0>, k_sep_p, k_deconv_r<64|128|256>, persistent grids): five frames of the
+    (k_sep_u<128,1,2,1,0>, k_sep_u<64,1,3,1,0>, k_sep_p, k_deconv_u<128,3> for deconv1, k_deconv_r<128|256>, persistent grids): five frames of the
     bench's own first batch -- same frame ids, same weights, uploaded from a page-locked staging buffer with
     pp_upload_points_async like the bench does -- against the oracle, head maps and detections."""
     B, N = 64, 16384
@@ -43,7 +43,7 @@ def test_bench_batch_b64_matches_oracle_per_frame(pp, hip_lib):
     w = pp.weights.init_weights(d, seed=7)                     # bench.py's weights
     eng.load_weights(w)
     tags = eng.layer_tags()
-    for want in ("k_sep_u<128,1,2,1,0>", "k_sep_u<64,1,3,1,0>", "k_sep_p", "k_deconv_r<64>", "k_deconv_r<128>",
+    for want in ("k_sep_u<128,1,2,1,0>", "k_sep_u<64,1,3,1,0>", "k_sep_p", "k_deconv_u<128,3>", "k_deconv_r<128>",
                  "k_deconv_r<256>"):
         assert any(t.startswith(want + ":") for t in tags), (want, tags)
     frames = [pp.synth.d435i_cloud(i, N, d.num_point_features) for i in pp.frame_shard.rank_frames(0, 1, B)]
