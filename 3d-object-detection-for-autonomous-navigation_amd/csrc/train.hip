@@ -41,7 +41,7 @@ typedef float tf32x16 __attribute__((ext_vector_type(16)));
 // 2-frame batches (every launch is a few microseconds: more workgroups only add dispatch time), up to TR_NPART_MAX
 // for large per-GPU batches, where 256 workgroups leave the chip a quarter full.  Chosen per step by train_step.
 #define TR_NPART_MAX 2048
-static int g_tr_npart = 256;
+static thread_local int g_tr_npart = 256;   // (per-step scratch state is thread-local: distinct handles may step on distinct threads)
 #define TR_NPART g_tr_npart
 
 // ------------------------------------------------------------------------------------------------------------
@@ -435,8 +435,8 @@ struct TMulti {
     int block_start[TR_MULTI_MAX + 1];
     int njobs;
 };
-static std::vector<ReduceJob> g_jobs;     // this step's deferred reductions (train_step resets it)
-static long g_arena_used = 0;             // floats of cx.gemm_part handed out to them
+static thread_local std::vector<ReduceJob> g_jobs;     // this step's deferred reductions (train_step resets it)
+static thread_local long g_arena_used = 0;             // floats of cx.gemm_part handed out to them
 
 __global__ __launch_bounds__(256) void k_tr_reduce_multi(TMulti m) {
     __shared__ float ssum[4][64];
@@ -500,7 +500,7 @@ static void launch_gemm2(const TGemm2& a2, bool akc, bool bkc, dim3 grid, hipStr
 }
 
 // rows of the statistics partials a forward product leaves ([tiles][2][N]; 0: the split kernel did not run)
-static int g_last_stat_tiles = 0;
+static thread_local int g_last_stat_tiles = 0;
 
 // defer: a split-K product whose result only the optimizer reads (weight gradients) keeps its partial tiles in a
 // region of its own and is reduced by the step's one deferred-reduction launch

@@ -529,6 +529,8 @@ def test_depthwise_once_kernel_ragged_tiles(pp, hip_lib):
     big.load_weights(w)
     tags = big.layer_tags()
     assert sum(t.startswith("k_sep_p:") for t in tags) == 5, tags
+    # the same shape ends inside a tile for k_deconv_r too (6 600 deconv3 pixels = 51.6 tiles, 832 units on 416 workgroups)
+    assert any(t.startswith("k_deconv_r<256>:") for t in tags) and any(t.startswith("k_deconv_r<128>:") for t in tags), tags
     cfg1 = copy.deepcopy(cfg)
     one = pp.Engine(cfg1, max_batch=1, max_points_per_frame=4096)
     one.load_weights(w)
@@ -548,5 +550,35 @@ def test_depthwise_once_kernel_ragged_tiles(pp, hip_lib):
         ref = util_ref.oracle_detect(d, w, [frames[i]], rect, trv, p2)
         for k in ("box_preds", "cls_preds", "dir_cls_preds"):
             np.testing.assert_allclose(imb[k][i], ref["preds"][k][0], rtol=0, atol=TOL)
+    big.close()
+    one.close()
+
+
+@pytest.mark.parametrize("B", [5, 33])
+def test_deconv_r_unit_runs_at_odd_batches(pp, hip_lib, B):
+    """k_deconv_r cuts the (tile, tap) units of a layer into equal runs per workgroup: batches whose unit count does not
+    divide (B = 5: deconv3 has 12.5 tiles, 208 units, one per workgroup; B = 33: 1 328 units, 3 per workgroup with a short
+    last run) -- head maps against the same frames run alone, and against the oracle for one frame."""
+    cfg = pp.config.pedestrian_d435i_config(B)
+    big = pp.Engine(cfg, max_batch=B, max_points_per_frame=8192)
+    d = big.d
+    w = pp.weights.init_weights(d, seed=17)
+    big.load_weights(w)
+    tags = big.layer_tags()
+    assert any(t.startswith("k_deconv_r<256>:") for t in tags) and any(t.startswith("k_deconv_r<128>:") for t in tags), tags
+    one = pp.Engine(pp.config.pedestrian_d435i_config(1), max_batch=1, max_points_per_frame=8192)
+    one.load_weights(w)
+    frames = [pp.synth.d435i_cloud(700 + i, 5000 + 37 * i) for i in range(B)]
+    rect, trv, p2 = pp.synth.default_calib()
+    big.detect(frames, np.stack([rect] * B), np.stack([trv] * B))
+    imb = big.intermediates()
+    for i in (0, B // 2, B - 1):
+        one.detect([frames[i]], rect[None], trv[None])
+        im1 = one.intermediates()
+        for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+            np.testing.assert_allclose(im1[k][0], imb[k][i], rtol=2e-5, atol=2e-5, err_msg=f"frame {i} {k}")
+    ref = util_ref.oracle_detect(d, w, [frames[B - 1]], rect, trv, p2)
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        np.testing.assert_allclose(imb[k][B - 1], ref["preds"][k][0], rtol=0, atol=TOL, err_msg=k)
     big.close()
     one.close()
