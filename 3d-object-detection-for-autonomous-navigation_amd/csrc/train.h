@@ -45,6 +45,7 @@ struct TrainCtx {
     float* pfn_stats;    // [C][2]
     float* pfn_sums;     // [2][C]
     float* pfn_nrows;    // [1] rows of the padded PFN tensor (pillars of the batch * T), computed on the device
+    int* pfn_prefix;     // [B + 1] exclusive prefix of the frames' pillar counts
     float* canvas;       // [B][ny][nx][C]
     float* dcanvas;
     // RPN

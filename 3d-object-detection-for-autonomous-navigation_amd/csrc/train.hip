@@ -909,7 +909,15 @@ struct PfnT {
     const int* pillar_cell;    // [batch][max_voxels] linear (z, y, x) cell
     const int* npillars;       // [batch]
     const float* W;            // [FA][C]
+    const int* pprefix;        // [batch + 1] exclusive prefix of npillars (k_tr_pfn_rows): the kernels walk the batch's
+                               // REAL pillars, not the batch * max_voxels slots (12 000 per frame, a quarter of them used)
 };
+// global pillar number gp -> (frame, pillar of the frame); bcur: the wave's frame cursor (gp only grows)
+__device__ __forceinline__ void pillar_of(const PfnT& p, int gp, int& bcur, int& b, int& pid) {
+    while (gp >= p.pprefix[bcur + 1]) ++bcur;
+    b = bcur;
+    pid = gp - p.pprefix[bcur];
+}
 
 // the decorated features of point j of a pillar (wave-uniform inputs): raw F | xyz - mean | xy - centre | [norm]
 // (f[0..9], unused tail zero; written with selects so that f stays in registers)
@@ -933,10 +941,8 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 
 // pillar geometry shared by the PFN kernels: frame, pillar id -> row range, mean, centre
 struct PillarInfo { int b, pid, n; long row0; float mx, my, mz, cx, cy; };
-__device__ __forceinline__ bool pillar_info(const PfnT& p, long gp, int lane, PillarInfo& o) {
-    o.b = (int)(gp / p.max_voxels);
-    o.pid = (int)(gp - (long)o.b * p.max_voxels);
-    if (o.b >= p.batch || o.pid >= p.npillars[o.b]) return false;
+__device__ __forceinline__ bool pillar_info(const PfnT& p, int gp, int lane, PillarInfo& o, int& bcur) {
+    pillar_of(p, gp, bcur, o.b, o.pid);
     const int* ps = p.pillar_start + (size_t)o.b * (p.max_voxels + 1);
     const int start = ps[o.pid];
     o.n = min(ps[o.pid + 1] - start, p.T);
@@ -970,10 +976,11 @@ __global__ __launch_bounds__(256) void k_tr_pfn_lin(PfnT p, float* __restrict__ 
     float s1[CPL], s2[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) s1[q] = s2[q] = 0.f;
-    const long total = (long)p.batch * p.max_voxels;
-    for (long gp = (long)blockIdx.x * 4 + wave; gp < total; gp += (long)gridDim.x * 4) {
+    const int total = p.pprefix[p.batch];
+    int bcur = 0;
+    for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
         PillarInfo pi;
-        if (!pillar_info(p, gp, lane, pi)) continue;
+        if (!pillar_info(p, gp, lane, pi, bcur)) continue;
         for (int j = 0; j < pi.n; ++j) {
             float f[10];
             pfn_row_features<CPL>(p, p.pts_sorted + (size_t)(pi.row0 + j) * p.F, pi.mx, pi.my, pi.mz, pi.cx, pi.cy, f);
@@ -1012,10 +1019,11 @@ __global__ __launch_bounds__(256) void k_tr_pfn_max(PfnT p, const float* __restr
         sc[q] = inv;
         sh[q] = (c < C) ? beta[c] - stats[2 * c] * inv : 0.f;
     }
-    const long total = (long)p.batch * p.max_voxels;
-    for (long gp = (long)blockIdx.x * 4 + wave; gp < total; gp += (long)gridDim.x * 4) {
-        const int b = (int)(gp / p.max_voxels), pid = (int)(gp - (long)b * p.max_voxels);
-        if (pid >= p.npillars[b]) continue;
+    const int total = p.pprefix[p.batch];
+    int bcur = 0;
+    for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
+        int b, pid;
+        pillar_of(p, gp, bcur, b, pid);
         const int* ps = p.pillar_start + (size_t)b * (p.max_voxels + 1);
         const int start = ps[pid];
         const int n = min(ps[pid + 1] - start, p.T);
@@ -1032,8 +1040,8 @@ __global__ __launch_bounds__(256) void k_tr_pfn_max(PfnT p, const float* __restr
             }
             if (n < p.T && sh[q] > best) { best = sh[q]; bi = -1; }   // a zero-padded row: Dense(0) = 0 -> BN
             if (!(best > 0.f)) { best = 0.f; bi = -2; }
-            feat[(size_t)gp * C + c] = best;
-            arg[(size_t)gp * C + c] = bi;
+            feat[((size_t)b * p.max_voxels + pid) * C + c] = best;     // rows of feat / arg: frame * max_voxels + pillar
+            arg[((size_t)b * p.max_voxels + pid) * C + c] = bi;
         }
     }
 }
@@ -1069,18 +1077,19 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_reduce(PfnT p, const float* 
     float s1[CPL], s2[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) s1[q] = s2[q] = 0.f;
-    const long total = (long)p.batch * p.max_voxels;
+    const int total = p.pprefix[p.batch];
+    int bcur = 0;
     const int ncanvas = p.nx * p.ny;
-    for (long gp = (long)blockIdx.x * 4 + wave; gp < total; gp += (long)gridDim.x * 4) {
-        const int b = (int)(gp / p.max_voxels), pid = (int)(gp - (long)b * p.max_voxels);
-        if (pid >= p.npillars[b]) continue;
+    for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
+        int b, pid;
+        pillar_of(p, gp, bcur, b, pid);
         const int cell = p.pillar_cell[(size_t)b * p.max_voxels + pid] % ncanvas;    // (y, x): the z index drops out
         const long row0 = (long)p.offsets[b] + p.pillar_start[(size_t)b * (p.max_voxels + 1) + pid];
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = lane * CPL + q;
             if (c >= C) continue;
-            const int a = arg[(size_t)gp * C + c];
+            const int a = arg[((size_t)b * p.max_voxels + pid) * C + c];
             if (a == -2) continue;
             const float g = dcanvas[((size_t)b * ncanvas + cell) * C + c];
             const float y = (a >= 0) ? Y[(size_t)(row0 + a) * C + c] : 0.f;
@@ -1123,18 +1132,19 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* _
         m1[q] = ok ? sums[c] / n_rows : 0.f;
         m2[q] = ok ? sums[C + c] / n_rows : 0.f;
     }
-    const long total = (long)p.batch * p.max_voxels;
+    const int total = p.pprefix[p.batch];
+    int bcur = 0;
     const int ncanvas = p.nx * p.ny;
-    for (long gp = (long)blockIdx.x * 4 + wave; gp < total; gp += (long)gridDim.x * 4) {
+    for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
         PillarInfo pi;
-        if (!pillar_info(p, gp, lane, pi)) continue;
+        if (!pillar_info(p, gp, lane, pi, bcur)) continue;
         const int cell = p.pillar_cell[(size_t)pi.b * p.max_voxels + pi.pid] % ncanvas;
         float g[CPL];
         int a[CPL];
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = lane * CPL + q;
-            a[q] = (c < C) ? arg[(size_t)gp * C + c] : -2;
+            a[q] = (c < C) ? arg[((size_t)pi.b * p.max_voxels + pi.pid) * C + c] : -2;
             g[q] = (c < C && a[q] >= 0) ? dcanvas[((size_t)pi.b * ncanvas + cell) * C + c] : 0.f;
         }
         for (int j = 0; j < pi.n; ++j) {
@@ -1304,17 +1314,21 @@ void bn_relu_backward(const TrainCtx& cx, const float* dA, int ld, int co_off, R
 }
 
 // n_rows[0] = (sum of the frames' pillar counts) * T: the rows of the reference's padded [P, T, C] tensor
-__global__ void k_tr_pfn_rows(const int* __restrict__ npillars, int batch, int T, float* __restrict__ n_rows) {
+// ... and prefix[b] = pillars of the frames before b (prefix[batch] = all of them)
+__global__ void k_tr_pfn_rows(const int* __restrict__ npillars, int batch, int T, float* __restrict__ n_rows,
+                              int* __restrict__ prefix) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        long tot = 0;
-        for (int b = 0; b < batch; ++b) tot += npillars[b];
+        int tot = 0;
+        for (int b = 0; b < batch; ++b) { prefix[b] = tot; tot += npillars[b]; }
+        prefix[batch] = tot;
         n_rows[0] = (float)tot * (float)T;
     }
 }
 
 template <int CPL>
 void pfn_forward(const TrainCtx& cx, const PfnT& p, const Lookup& L) {
-    PP_LAUNCH("k_tr_pfn_rows", k_tr_pfn_rows, dim3(1), dim3(64), 0, cx.stream, p.npillars, p.batch, p.T, cx.pfn_nrows);
+    PP_LAUNCH("k_tr_pfn_rows", k_tr_pfn_rows, dim3(1), dim3(64), 0, cx.stream, p.npillars, p.batch, p.T, cx.pfn_nrows,
+              cx.pfn_prefix);
     PP_LAUNCH("k_tr_pfn_lin", (k_tr_pfn_lin<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, cx.pfn_y, cx.part);
     bn_finalize(cx, cx.part, TR_NPART, p.C, 0.f, cx.pfn_nrows, 0.01f, 0, cx.pfn_stats, L.s("pfn/bn/moving_mean"),
                 L.s("pfn/bn/moving_variance"), 1);
@@ -1367,7 +1381,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
     p.with_distance = s.with_dist;
     p.vx = s.vx; p.vy = s.vy; p.x_off = s.x_off; p.y_off = s.y_off;
     p.pts_sorted = cx.pts_sorted; p.offsets = cx.offsets; p.pillar_start = cx.pillar_start; p.pillar_cell = cx.pillar_cell;
-    p.npillars = cx.npillars; p.W = L.p("pfn/dense/kernel");
+    p.npillars = cx.npillars; p.W = L.p("pfn/dense/kernel"); p.pprefix = cx.pfn_prefix;
     const int cpl = (s.C + 63) / 64;
     if (cpl == 1) pfn_forward<1>(cx, p, L);
     else if (cpl == 2) pfn_forward<2>(cx, p, L);
