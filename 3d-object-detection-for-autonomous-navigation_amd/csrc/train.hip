@@ -671,7 +671,9 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd_in(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_tr_dw_bwd_w(const float* __restrict__ X, const float* __restrict__ dD,
                                                      float* __restrict__ part, int B, int ih, int iw, int oh, int ow,
                                                      int C, int S) {
-    __shared__ float4 sred[9 * 256];
+    __shared__ float4 sred[3 * 256];                     // three taps at a time: 12 KB, eight workgroups per CU (the
+                                                         // kernel is a few memory round trips per thread: it lives on
+                                                         // resident waves; 36 KB for all nine taps allowed four)
     const int tid = threadIdx.x;
     const int cq = C >> 2;                               // channel quads: 8 .. 64 (C in {32, 64, 128, 256})
     const int q = tid % cq, ps = tid / cq, nps = 256 / cq;
@@ -709,17 +711,21 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd_w(const float* __restrict__ X
         while (x >= ow) { x -= ow; if (++y == oh) { y = 0; ++b; } }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) sred[t * 256 + tid] = acc[t];
-    __syncthreads();
-    if (ps == 0) {
+    for (int t0 = 0; t0 < 9; t0 += 3) {
+        if (t0) __syncthreads();                         // the previous three taps have been read
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float4 v = acc[t];
-            for (int k = 1; k < nps; ++k) {
-                const float4 o = sred[t * 256 + tid + k * cq];
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        for (int t = 0; t < 3; ++t) sred[t * 256 + tid] = acc[t0 + t];
+        __syncthreads();
+        if (ps == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float4 v = acc[t0 + t];
+                for (int k = 1; k < nps; ++k) {
+                    const float4 o = sred[t * 256 + tid + k * cq];
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 9 + t0 + t) * C + 4 * q) = v;
             }
-            *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 9 + t) * C + 4 * q) = v;
         }
     }
 }
