@@ -1670,14 +1670,16 @@ int train_buffers(pp_engine* e) {
     A1(dalloc(e, &cx.canvas, B * s.ny * s.nx * s.C));
     A1(dalloc(e, &cx.dcanvas, B * s.ny * s.nx * s.C));
     size_t max_z = 1, max_d = 1;
-    cx.lbuf.assign(s.layers.size(), TrainLayerBuf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+    cx.lbuf.assign(s.layers.size(), TrainLayerBuf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
     for (size_t i = 0; i < s.layers.size(); ++i) {
         const LayerDesc& l = s.layers[i];
         TrainLayerBuf& tb = cx.lbuf[i];
         if (l.kind == LAYER_SEP) {
             const size_t rows = B * l.out_h * l.out_w;
             A1(dalloc(e, &tb.D, rows * l.cin)); A1(dalloc(e, &tb.Z, rows * l.cout));
-            A1(dalloc(e, &tb.A, rows * l.cout)); A1(dalloc(e, &tb.dA, rows * l.cout));
+            // the activation tensor only where it is read as one: the layer in front of a transposed convolution
+            if (i + 1 < s.layers.size() && s.layers[i + 1].kind == LAYER_DECONV) A1(dalloc(e, &tb.A, rows * l.cout));
+            A1(dalloc(e, &tb.dA, rows * l.cout));
             max_z = std::max(max_z, rows * l.cout); max_d = std::max(max_d, rows * l.cin);
         } else if (l.kind == LAYER_DECONV) {
             const size_t n = B * l.in_h * l.in_w * l.k * l.k * l.cout;
@@ -1687,6 +1689,7 @@ int train_buffers(pp_engine* e) {
             continue;
         }
         A1(dalloc(e, &tb.stats, (size_t)2 * l.cout)); A1(dalloc(e, &tb.sums, (size_t)2 * l.cout));
+        A1(dalloc(e, &tb.coef, (size_t)l.cout));
     }
     A1(dalloc(e, &cx.cat, B * HW * s.CC)); A1(dalloc(e, &cx.dcat, B * HW * s.CC));
     A1(dalloc(e, &cx.head_w, (size_t)s.CC * PP_HEAD_COLS)); A1(dalloc(e, &cx.head_b, (size_t)PP_HEAD_COLS));

@@ -23,10 +23,12 @@ struct TrainShape {
 struct TrainLayerBuf {
     float* D;       // depthwise output [rows][cin] (separable layers)
     float* Z;       // pre-BatchNorm GEMM output [rows][cout] / [pixels][k*k*cout]
-    float* A;       // activation [rows][cout] (separable layers; the deconvs write into the concat buffer)
+    float* A;       // activation [rows][cout]: block-final separable layers only (the transposed convolution and the next
+                    // block read it as a tensor; in-block readers evaluate relu(bn(Z)) from Z and coef); NULL otherwise
     float* dA;      // gradient of A (separable layers)
     float* stats;   // [cout][2] batch mean, 1/sqrt(var + eps)
     float* sums;    // [2][cout] scratch of the reductions
+    float4* coef;   // [cout] (sc, sh, inv, -mean * inv): act = z * sc + sh, zhat = z * inv + nmi (k_tr_bn_finalize)
 };
 
 struct TrainCtx {

@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void k_tr_gemm(TGemm g) {
 typedef __bf16 tbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 tbf16x2 __attribute__((ext_vector_type(2)));
 typedef float tf32x2 __attribute__((ext_vector_type(2)));
-#define T2_LDR 40                         // bfloat16 per LDS row: 32 of the chunk + 8 pad (80 bytes)
+// bfloat16 per LDS row: the KCH of a chunk + 8 pad (80-byte rows for KCH = 32, 144-byte rows for 64: the 16-byte
+// fragment reads of 16 consecutive rows fall on 16 distinct bank quads either way)
+#define T2_LDR(KCH) ((KCH) + 8)
 
 // v[0..1] -> packed bfloat16 pairs of the three pieces
 __device__ __forceinline__ void t2_split2(float v0, float v1, unsigned& hi, unsigned& mid, unsigned& lo) {
@@ -161,16 +163,18 @@ __device__ __forceinline__ void t2_split2(float v0, float v1, unsigned& hi, unsi
     lo = __builtin_bit_cast(unsigned, l);
 }
 
-// One operand tile of ROWS (m or n) x 32 (k) per chunk, 256 threads.  KC form: a thread owns EPT consecutive k of one
+// One operand tile of ROWS (m or n) x KCH (k) per chunk, 256 threads.  KC form: a thread owns EPT consecutive k of one
 // row; transposed form: 4 consecutive rows x EPT / 4 consecutive k.
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int KCH>
 struct T2Stage {
-    static constexpr int EPT = ROWS / 8;                   // elements per thread per chunk: 16 (128 rows) or 8 (64)
+    static constexpr int EPT = ROWS * KCH / 256;           // elements per thread per chunk: 8, 16 or 32
+    static constexpr int LDR = T2_LDR(KCH);
+    static_assert(KC || EPT == 8 || EPT == 16, "transposed staging: 2 or 4 k per thread");
     float v[EPT];
     // p(r, k) = base[r * sr + k * sk]; rows >= nrows and k >= kend read as zero
     __device__ __forceinline__ void load(const float* __restrict__ base, long sr, long sk, int row0, int nrows, int k0, int kend, int tid) {
         if (KC) {
-            constexpr int TPR = 32 / EPT;
+            constexpr int TPR = KCH / EPT;
             const int r = row0 + tid / TPR, k = k0 + (tid % TPR) * EPT;
             const float* q = base + (long)r * sr + k;
 #pragma unroll
@@ -190,12 +194,12 @@ struct T2Stage {
             }
         }
     }
-    // split and store into the three LDS planes plane[p][row][T2_LDR]
+    // split and store into the three LDS planes plane[p][row][LDR]
     __device__ __forceinline__ void store(__bf16* __restrict__ lds, int tid) const {
-        constexpr int PL = ROWS * T2_LDR;
+        constexpr int PL = ROWS * LDR;
         if (KC) {
-            constexpr int TPR = 32 / EPT;
-            __bf16* d = lds + (tid / TPR) * T2_LDR + (tid % TPR) * EPT;
+            constexpr int TPR = KCH / EPT;
+            __bf16* d = lds + (tid / TPR) * LDR + (tid % TPR) * EPT;
 #pragma unroll
             for (int j = 0; j < EPT; j += 8) {
                 unsigned h[4], m[4], l[4];
@@ -207,20 +211,20 @@ struct T2Stage {
             }
         } else {
             constexpr int KPT = EPT / 4, RG = ROWS / 4;
-            __bf16* d = lds + ((tid % RG) * 4) * T2_LDR + (tid / RG) * KPT;
+            __bf16* d = lds + ((tid % RG) * 4) * LDR + (tid / RG) * KPT;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                  // row r + i: KPT consecutive k
                 unsigned h[KPT / 2], m[KPT / 2], l[KPT / 2];
 #pragma unroll
                 for (int j = 0; j < KPT; j += 2) t2_split2(v[4 * j + i], v[4 * (j + 1) + i], h[j / 2], m[j / 2], l[j / 2]);
                 if (KPT == 4) {
-                    *reinterpret_cast<uint2*>(d + i * T2_LDR) = make_uint2(h[0], h[KPT / 2 - 1]);
-                    *reinterpret_cast<uint2*>(d + PL + i * T2_LDR) = make_uint2(m[0], m[KPT / 2 - 1]);
-                    *reinterpret_cast<uint2*>(d + 2 * PL + i * T2_LDR) = make_uint2(l[0], l[KPT / 2 - 1]);
+                    *reinterpret_cast<uint2*>(d + i * LDR) = make_uint2(h[0], h[KPT / 2 - 1]);
+                    *reinterpret_cast<uint2*>(d + PL + i * LDR) = make_uint2(m[0], m[KPT / 2 - 1]);
+                    *reinterpret_cast<uint2*>(d + 2 * PL + i * LDR) = make_uint2(l[0], l[KPT / 2 - 1]);
                 } else {
-                    *reinterpret_cast<unsigned*>(d + i * T2_LDR) = h[0];
-                    *reinterpret_cast<unsigned*>(d + PL + i * T2_LDR) = m[0];
-                    *reinterpret_cast<unsigned*>(d + 2 * PL + i * T2_LDR) = l[0];
+                    *reinterpret_cast<unsigned*>(d + i * LDR) = h[0];
+                    *reinterpret_cast<unsigned*>(d + PL + i * LDR) = m[0];
+                    *reinterpret_cast<unsigned*>(d + 2 * PL + i * LDR) = l[0];
                 }
             }
         }
@@ -229,23 +233,24 @@ struct T2Stage {
 
 struct TGemm2 {
     TGemm g;
-    float* stat_part;    // [gridDim.y][2][N] column sums / sums of squares of the tile's rows, or NULL
+    float* stat_part;    // [grid.y][2][N] column sums / sums of squares of the tile's rows, or NULL
+    int gx, gy, gz;      // the product's workgroup grid (a launch may carry two products: k_tr_gemm2_pair)
 };
 
-template <int WM, int WN, bool AKC, bool BKC>
-__global__ __launch_bounds__(256, 2) void k_tr_gemm2(TGemm2 a2) {
+// one workgroup of one product: tile (bx, by), K slice bz; sA / sB: 3 * BM * LDR and 3 * BN * LDR bfloat16
+template <int WM, int WN, bool AKC, bool BKC, int KCH>
+__device__ __forceinline__ void t2_gemm_tile(const TGemm2& a2, int bx, int by, int bz, __bf16* __restrict__ sA,
+                                             __bf16* __restrict__ sB) {
     const TGemm& g = a2.g;
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int PLA = BM * T2_LDR, PLB = BN * T2_LDR;
-    __shared__ __attribute__((aligned(16))) __bf16 sA[3 * PLA];
-    __shared__ __attribute__((aligned(16))) __bf16 sB[3 * PLB];
+    constexpr int BM = 64 * WM, BN = 64 * WN, LDR = T2_LDR(KCH);
+    constexpr int PLA = BM * LDR, PLB = BN * LDR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, r32 = lane & 31;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.kper, kend = min(g.K, kbeg + g.kper);
-    T2Stage<BM, AKC> ra;
-    T2Stage<BN, BKC> rb;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int kbeg = bz * g.kper, kend = min(g.K, kbeg + g.kper);
+    T2Stage<BM, AKC, KCH> ra;
+    T2Stage<BN, BKC, KCH> rb;
     // A(m, k): row stride sam / k stride sak;  B(k, n) seen as rows n: row stride sbn, k stride sbk
     tf32x16 acc[WM][WN];
 #pragma unroll
@@ -258,30 +263,30 @@ __global__ __launch_bounds__(256, 2) void k_tr_gemm2(TGemm2 a2) {
         ra.load(g.A, g.sam, g.sak, m0, g.M, kbeg, kend, tid);
         rb.load(g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid);
     }
-    const __bf16* fa = sA + (wm * 32 * WM + r32) * T2_LDR + 8 * h;
-    const __bf16* fb = sB + (wn * 32 * WN + r32) * T2_LDR + 8 * h;
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    const __bf16* fa = sA + (wm * 32 * WM + r32) * LDR + 8 * h;
+    const __bf16* fb = sB + (wn * 32 * WN + r32) * LDR + 8 * h;
+    for (int k0 = kbeg; k0 < kend; k0 += KCH) {
         __syncthreads();                                   // the previous chunk's fragments have been read
         ra.store(sA, tid);
         rb.store(sB, tid);
         __syncthreads();
-        if (k0 + 32 < kend) {
-            ra.load(g.A, g.sam, g.sak, m0, g.M, k0 + 32, kend, tid);
-            rb.load(g.B, g.sbn, g.sbk, n0, g.N, k0 + 32, kend, tid);
+        if (k0 + KCH < kend) {
+            ra.load(g.A, g.sam, g.sak, m0, g.M, k0 + KCH, kend, tid);
+            rb.load(g.B, g.sbn, g.sbk, n0, g.N, k0 + KCH, kend, tid);
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KCH / 16; ++ks) {
             tbf16x8 ah[WM], am[WM], al[WM];
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
-                const __bf16* q = fa + i * 32 * T2_LDR + ks * 16;
+                const __bf16* q = fa + i * 32 * LDR + ks * 16;
                 ah[i] = *reinterpret_cast<const tbf16x8*>(q);
                 am[i] = *reinterpret_cast<const tbf16x8*>(q + PLA);
                 al[i] = *reinterpret_cast<const tbf16x8*>(q + 2 * PLA);
             }
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-                const __bf16* q = fb + j * 32 * T2_LDR + ks * 16;
+                const __bf16* q = fb + j * 32 * LDR + ks * 16;
                 const tbf16x8 bh = *reinterpret_cast<const tbf16x8*>(q);
                 const tbf16x8 bm = *reinterpret_cast<const tbf16x8*>(q + PLB);
                 const tbf16x8 bl = *reinterpret_cast<const tbf16x8*>(q + 2 * PLB);
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_tr_gemm2(TGemm2 a2) {
         for (int e = tid; e < 2 * BN; e += 256) {
             const int which = e / BN, col = e % BN;
             if (n0 + col < g.N)
-                a2.stat_part[((size_t)blockIdx.y * 2 + which) * g.N + n0 + col] = red[which * BN + col] + red[(2 + which) * BN + col];
+                a2.stat_part[((size_t)by * 2 + which) * g.N + n0 + col] = red[which * BN + col] + red[(2 + which) * BN + col];
         }
     }
 #pragma unroll
@@ -336,14 +341,41 @@ __global__ __launch_bounds__(256, 2) void k_tr_gemm2(TGemm2 a2) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m >= g.M) continue;
-                if (gridDim.z > 1) {
-                    g.Cpart[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+                if (a2.gz > 1) {
+                    g.Cpart[((size_t)bz * g.M + m) * g.N + n] = acc[i][j][r];
                 } else {
                     float* c = g.C + (size_t)m * g.ldc + n;
                     const float v = acc[i][j][r] + bv;
                     *c = g.accumulate ? (*c + v) : v;
                 }
             }
+    }
+}
+
+template <int WM, int WN, bool AKC, bool BKC, int KCH>
+__global__ __launch_bounds__(256, 2) void k_tr_gemm2(TGemm2 a2) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[3 * 64 * WM * T2_LDR(KCH)];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[3 * 64 * WN * T2_LDR(KCH)];
+    t2_gemm_tile<WM, WN, AKC, BKC, KCH>(a2, blockIdx.x, blockIdx.y, blockIdx.z, sA, sB);
+}
+
+// Two independent products in ONE launch (the weight- and the input-gradient product of a layer read the same dZ and
+// depend on nothing else: at the reference's 2-frame batch each is a handful of workgroups living on memory latency,
+// and a launch of its own costs as much as the product).  64 x 64 tiles, 64-wide chunks; workgroups [0, n1) run
+// product 1 (TN: A and B with unit stride across k), the rest product 2 (A along k; B2KC: B along k).
+template <bool B2KC>
+__global__ __launch_bounds__(256, 2) void k_tr_gemm2_pair(TGemm2 p1, TGemm2 p2) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[3 * 64 * T2_LDR(64)];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[3 * 64 * T2_LDR(64)];
+    const int n1 = p1.gx * p1.gy * p1.gz;
+    int id = (int)blockIdx.x;
+    if (id < n1) {
+        const int bx = id % p1.gx; id /= p1.gx;
+        t2_gemm_tile<1, 1, false, false, 64>(p1, bx, id % p1.gy, id / p1.gy, sA, sB);
+    } else {
+        id -= n1;
+        const int bx = id % p2.gx; id /= p2.gx;
+        t2_gemm_tile<1, 1, true, B2KC, 64>(p2, bx, id % p2.gy, id / p2.gy, sA, sB);
     }
 }
 
@@ -491,49 +523,80 @@ static bool train_split_gemm() {
     return v == 1;
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int KCH>
 static void launch_gemm2(const TGemm2& a2, bool akc, bool bkc, dim3 grid, hipStream_t s) {
-    if (akc && bkc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, true, true>), grid, dim3(256), 0, s, a2);
-    else if (akc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, true, false>), grid, dim3(256), 0, s, a2);
-    else if (bkc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, false, true>), grid, dim3(256), 0, s, a2);
-    else PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, false, false>), grid, dim3(256), 0, s, a2);
+    if (akc && bkc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, true, true, KCH>), grid, dim3(256), 0, s, a2);
+    else if (akc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, true, false, KCH>), grid, dim3(256), 0, s, a2);
+    else if (bkc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, false, true, KCH>), grid, dim3(256), 0, s, a2);
+    else PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, false, false, KCH>), grid, dim3(256), 0, s, a2);
 }
 
 // rows of the statistics partials a forward product leaves ([tiles][2][N]; 0: the split kernel did not run)
 static thread_local int g_last_stat_tiles = 0;
 
+// a launch with fewer workgroups than this lives on memory latency, not on throughput: 64-wide K chunks (half the
+// dependent load -> LDS -> MFMA rounds), and the two gradient products of a layer share one launch
+#define TR_LATENCY_WGS 512
+
+// C[M][N] (+)= A(m,k) * B(k,n) [+ bias(n)],  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
 // defer: a split-K product whose result only the optimizer reads (weight gradients) keeps its partial tiles in a
 // region of its own and is reduced by the step's one deferred-reduction launch
-static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
-                    long ldc, int M, int N, int K, const float* bias, int accumulate, int ksplit, float* stat_part = nullptr,
-                    bool defer = false) {
+struct GemmCall {
+    const float* A; long sam, sak;
+    const float* B; long sbk, sbn;
+    float* C; long ldc;
+    int M, N, K;
+    const float* bias;
+    int accumulate, ksplit;
+    float* stat_part;
+    bool defer;
+};
+
+static bool gemm2_eligible(const GemmCall& c) {
+    // the split-precision kernel: unit stride on one axis of each operand, 16-byte aligned rows
+    const bool akc = c.sak == 1, bkc = c.sbk == 1;
+    const bool a_ok = akc ? (c.sam % 4 == 0) : (c.sam == 1 && c.sak % 4 == 0 && c.M % 4 == 0);
+    const bool b_ok = bkc ? (c.sbn % 4 == 0) : (c.sbn == 1 && c.sbk % 4 == 0 && c.N % 4 == 0);
+    return train_split_gemm() && a_ok && b_ok && c.K % 4 == 0 && ((uintptr_t)c.A % 16 == 0) && ((uintptr_t)c.B % 16 == 0);
+}
+
+static TGemm gemm_args(const TrainCtx& cx, const GemmCall& c, int& ksplit) {
     TGemm g;
-    g.A = A; g.sam = sam; g.sak = sak; g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc;
-    g.M = M; g.N = N; g.K = K; g.bias = bias; g.accumulate = accumulate;
-    if (ksplit < 1) ksplit = 1;
+    g.A = c.A; g.sam = c.sam; g.sak = c.sak; g.B = c.B; g.sbk = c.sbk; g.sbn = c.sbn; g.C = c.C; g.ldc = c.ldc;
+    g.M = c.M; g.N = c.N; g.K = c.K; g.bias = c.bias; g.accumulate = c.accumulate;
+    ksplit = std::max(1, c.ksplit);
     // partial tiles go to the free tail of the arena (behind the regions of this step's deferred reductions)
     const long avail = cx.gemm_part_floats - g_arena_used;
-    while (ksplit > 1 && (long)ksplit * M * N > avail) --ksplit;
+    while (ksplit > 1 && (long)ksplit * c.M * c.N > avail) --ksplit;
     g.Cpart = cx.gemm_part + g_arena_used;
+    g.kper = c.K;
+    return g;
+}
+
+static void gemm_finish_split(const TrainCtx& cx, const GemmCall& c, const TGemm& g, int ks) {
+    const long n = (long)c.M * c.N;
+    if (c.defer) {
+        g_jobs.push_back(ReduceJob{g.Cpart, c.C, n, n, c.ldc, ks, c.N, c.accumulate, 1.0f});
+        g_arena_used += ((long)ks * n + 63) / 64 * 64;
+    } else {
+        tr_reduce(cx.stream, (const float*)g.Cpart, ks, n, n, c.C, c.ldc, c.N, c.accumulate, 1.0f);
+    }
+}
+
+static void tr_gemm(const TrainCtx& cx, const GemmCall& c) {
+    int ksplit;
+    TGemm g = gemm_args(cx, c, ksplit);
     g_last_stat_tiles = 0;
-    auto finish_split = [&](int ks) {
-        const long n = (long)M * N;
-        if (defer) {
-            g_jobs.push_back(ReduceJob{g.Cpart, C, n, n, ldc, ks, N, accumulate, 1.0f});
-            g_arena_used += ((long)ks * n + 63) / 64 * 64;
-        } else {
-            tr_reduce(cx.stream, (const float*)g.Cpart, ks, n, n, C, ldc, N, accumulate, 1.0f);
-        }
-    };
-    // the split-precision kernel: unit stride on one axis of each operand, 16-byte aligned rows
-    const bool akc = sak == 1, bkc = sbk == 1;
-    const bool a_ok = akc ? (sam % 4 == 0) : (sam == 1 && sak % 4 == 0 && M % 4 == 0);
-    const bool b_ok = bkc ? (sbn % 4 == 0) : (sbn == 1 && sbk % 4 == 0 && N % 4 == 0);
-    if (train_split_gemm() && a_ok && b_ok && K % 4 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0)) {
+    const int M = c.M, N = c.N, K = c.K;
+    if (gemm2_eligible(c)) {
+        const bool akc = c.sak == 1, bkc = c.sbk == 1;
         int kper = ((K + ksplit - 1) / ksplit + 31) / 32 * 32;
+        const long small = (long)((M + 63) / 64) * ((N + 63) / 64) * ((K + kper - 1) / kper);
+        const bool wide = small < TR_LATENCY_WGS;        // 64-wide chunks
+        if (wide) kper = (kper + 63) / 64 * 64;
         ksplit = (K + kper - 1) / kper;
         g.kper = kper;
-        TGemm2 a2{g, (ksplit == 1) ? stat_part : nullptr};
+        TGemm2 a2{g, (ksplit == 1) ? c.stat_part : nullptr, 0, 0, ksplit};
         // big tiles when they still fill the chip (two workgroups per CU), small ones otherwise; 64-column layers keep
         // 128 rows per workgroup (two accumulator tiles per wave share every weight fragment)
         const long big = (long)((M + 127) / 128) * ((N + 127) / 128) * ksplit;
@@ -543,17 +606,18 @@ static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, cons
         if (N >= 128 && big >= thr) {
             dim3 grid((N + 127) / 128, (M + 127) / 128, ksplit);
             if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
-            launch_gemm2<2, 2>(a2, akc, bkc, grid, cx.stream);
+            launch_gemm2<2, 2, 32>(a2, akc, bkc, grid, cx.stream);
         } else if (tall >= thr) {
             dim3 grid((N + 63) / 64, (M + 127) / 128, ksplit);
             if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
-            launch_gemm2<2, 1>(a2, akc, bkc, grid, cx.stream);
+            launch_gemm2<2, 1, 32>(a2, akc, bkc, grid, cx.stream);
         } else {
             dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
             if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
-            launch_gemm2<1, 1>(a2, akc, bkc, grid, cx.stream);
+            if (wide) launch_gemm2<1, 1, 64>(a2, akc, bkc, grid, cx.stream);
+            else launch_gemm2<1, 1, 32>(a2, akc, bkc, grid, cx.stream);
         }
-        if (ksplit > 1) finish_split(ksplit);
+        if (ksplit > 1) gemm_finish_split(cx, c, g, ksplit);
         return;
     }
     int kper = ((K + ksplit - 1) / ksplit + 15) / 16 * 16;
@@ -561,7 +625,51 @@ static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, cons
     g.kper = kper;
     dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
     PP_LAUNCH("k_tr_gemm", k_tr_gemm, grid, dim3(256), 0, cx.stream, g);
-    if (ksplit > 1) finish_split(ksplit);
+    if (ksplit > 1) gemm_finish_split(cx, c, g, ksplit);
+}
+
+static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
+                    long ldc, int M, int N, int K, const float* bias, int accumulate, int ksplit, float* stat_part = nullptr,
+                    bool defer = false) {
+    tr_gemm(cx, GemmCall{A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, bias, accumulate, ksplit, stat_part, defer});
+}
+
+// The weight-gradient product (w: TN form, split-K, deferred reduction) and the input-gradient product (d) of one
+// layer.  While both are a few hundred workgroups they go out as ONE launch (k_tr_gemm2_pair); otherwise one by one.
+static void tr_gemm_pair(const TrainCtx& cx, const GemmCall& w, const GemmCall& d) {
+    const bool forms = w.sak != 1 && w.sbk != 1 && d.sak == 1;
+    if (forms && gemm2_eligible(w) && gemm2_eligible(d) && w.defer && w.stat_part == nullptr && d.stat_part == nullptr) {
+        auto plan = [](const GemmCall& c, int ks, int& kper, int& nks) {
+            kper = ((c.K + ks - 1) / ks + 63) / 64 * 64;
+            nks = (c.K + kper - 1) / kper;
+            return (long)((c.M + 63) / 64) * ((c.N + 63) / 64) * nks;
+        };
+        int ks1, ks2, kper1, kper2, n1, n2;
+        TGemm g1 = gemm_args(cx, w, ks1);
+        const long wg1 = plan(w, ks1, kper1, n1);
+        // (the second product's partial tiles, if it is split, lie behind the first one's region)
+        const long region1 = (n1 > 1) ? ((long)n1 * w.M * w.N + 63) / 64 * 64 : 0;
+        const long saved = g_arena_used;
+        g_arena_used += region1;
+        TGemm g2 = gemm_args(cx, d, ks2);
+        g_arena_used = saved;
+        const long wg2 = plan(d, ks2, kper2, n2);
+        if (wg1 + wg2 < 2 * TR_LATENCY_WGS) {
+            g1.kper = kper1; g2.kper = kper2;
+            TGemm2 p1{g1, nullptr, (w.N + 63) / 64, (w.M + 63) / 64, n1};
+            TGemm2 p2{g2, nullptr, (d.N + 63) / 64, (d.M + 63) / 64, n2};
+            g_last_stat_tiles = 0;
+            if (d.sbk == 1)
+                PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<true>), dim3((unsigned)(wg1 + wg2)), dim3(256), 0, cx.stream, p1, p2);
+            else
+                PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<false>), dim3((unsigned)(wg1 + wg2)), dim3(256), 0, cx.stream, p1, p2);
+            if (n1 > 1) gemm_finish_split(cx, w, g1, n1);                 // deferred: its region is now taken
+            if (n2 > 1) gemm_finish_split(cx, d, g2, n2);                 // reduced at once (from behind that region)
+            return;
+        }
+    }
+    tr_gemm(cx, w);
+    tr_gemm(cx, d);
 }
 
 // weight gradients: K = rows (pixels); enough slices to fill the chip, bounded by the partial buffer
@@ -571,6 +679,14 @@ static int wgrad_split(const TrainCtx& cx, int M, int N, int K) {
     want = std::min<long>(want, (K + 255) / 256);
     while (want > 1 && want * (long)M * N > cx.gemm_part_floats) --want;
     return (int)want;
+}
+
+// input gradients with a long K (the transposed convolutions: K = taps * channels) on a map of few tiles: K slices of
+// >= 256 until the launch has a workgroup or two per CU (the partial tiles are added at once: the next kernel reads C)
+static int dgrad_split(int M, int N, int K) {
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles >= 256) return 1;
+    return (int)std::max<long>(1, std::min<long>(512 / tiles, K / 256));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -601,9 +717,11 @@ __global__ __launch_bounds__(256) void k_tr_fill(float* p, long n, float v) {
 
 // depthwise 3x3, symmetric padding 1, stride S (ZeroPadding2D(1) + 'valid' == 'same' for stride 1):
 // D[b,y,x,c] = sum_t X[b, y*S-1+dy, x*S-1+dx, c] * w[t][c]
+// coef != NULL: X is the PRE-BatchNorm map Z of the layer before and the activation relu(z * sc + sh) is evaluated on the
+// way in (the activation tensor of an in-block layer is never written: k_tr_bn_relu's pass and its output are gone)
 __global__ __launch_bounds__(256) void k_tr_dw_fwd(const float* __restrict__ X, const float* __restrict__ w,
                                                    float* __restrict__ D, unsigned total, int ih, int iw, Div32 doh, Div32 dow,
-                                                   Div32 dc4, int C, int S) {
+                                                   Div32 dc4, int C, int S, const float4* __restrict__ coef) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;      // (pixel, channel quad); total < 2^32 (launcher)
     if (i >= total) return;
     unsigned p, cq, x, y, b;
@@ -612,6 +730,12 @@ __global__ __launch_bounds__(256) void k_tr_dw_fwd(const float* __restrict__ X, 
     divmod32(p, doh, b, y);
     const int c = (int)cq * 4;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool bn = coef != nullptr;                          // uniform
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float4 q = coef[c + j]; sc[j] = q.x; sh[j] = q.y; }
+    }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         const int yy = (int)y * S - 1 + dy;
@@ -620,7 +744,11 @@ __global__ __launch_bounds__(256) void k_tr_dw_fwd(const float* __restrict__ X, 
         for (int dx = 0; dx < 3; ++dx) {
             const int xx = (int)x * S - 1 + dx;
             if ((unsigned)xx >= (unsigned)iw) continue;
-            const float4 v = *reinterpret_cast<const float4*>(X + (((size_t)b * ih + yy) * iw + xx) * C + c);
+            float4 v = *reinterpret_cast<const float4*>(X + (((size_t)b * ih + yy) * iw + xx) * C + c);
+            if (bn) {
+                v.x = fmaxf(fmaf(v.x, sc[0], sh[0]), 0.f); v.y = fmaxf(fmaf(v.y, sc[1], sh[1]), 0.f);
+                v.z = fmaxf(fmaf(v.z, sc[2], sh[2]), 0.f); v.w = fmaxf(fmaf(v.w, sc[3], sh[3]), 0.f);
+            }
             const float4 k = *reinterpret_cast<const float4*>(w + (size_t)(dy * 3 + dx) * C + c);
             o.x = fmaf(v.x, k.x, o.x); o.y = fmaf(v.y, k.y, o.y); o.z = fmaf(v.z, k.z, o.z); o.w = fmaf(v.w, k.w, o.w);
         }
@@ -765,7 +893,8 @@ __global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict_
                                                         const float* __restrict__ n_rows_dev, float momentum,
                                                         int unbiased_moving, float* __restrict__ stats,
                                                         float* __restrict__ moving_mean, float* __restrict__ moving_var,
-                                                        int ntaps) {
+                                                        int ntaps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float4* __restrict__ coef) {
     const int l = threadIdx.x & (LPC - 1);
     const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     float s1 = 0.f, s2 = 0.f;
@@ -784,8 +913,13 @@ __global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict_
     const float mean = s1 / n_rows;
     float var = s2 / n_rows - mean * mean;
     var = fmaxf(var, 0.f);
+    const float inv = 1.0f / sqrtf(var + TR_EPS);
     stats[2 * c] = mean;
-    stats[2 * c + 1] = 1.0f / sqrtf(var + TR_EPS);
+    stats[2 * c + 1] = inv;
+    if (coef != nullptr) {      // what the consumers of Z evaluate: act = z * sc + sh, zhat = z * inv + nmi
+        const float sc = inv * gamma[c];
+        coef[c] = make_float4(sc, fmaf(-mean, sc, beta[c]), inv, -mean * inv);
+    }
     if (moving_mean != nullptr) {
         const float vm = (unbiased_moving && n_rows > 1.f) ? var * (n_rows / (n_rows - 1.f)) : var;
         moving_mean[c] = moving_mean[c] * momentum + mean * (1.f - momentum);
@@ -810,9 +944,8 @@ __device__ __forceinline__ long map_row(const RowMap& m, long r) {
     return ((long)(b * m.in_h * m.k + y * m.k + ti) * ((long)m.in_w * m.k)) + (long)(x * m.k + tj);
 }
 
-// A[map(r)][co_off + c] = relu((Z[r][c] - mean) * inv * gamma + beta)
-__global__ __launch_bounds__(256) void k_tr_bn_relu(const float* __restrict__ Z, long rows, int C, const float* __restrict__ stats,
-                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+// A[map(r)][co_off + c] = relu(Z[r][c] * sc + sh)   (coef[c] = (sc, sh, inv, -mean * inv), k_tr_bn_finalize)
+__global__ __launch_bounds__(256) void k_tr_bn_relu(const float* __restrict__ Z, long rows, int C, const float4* __restrict__ coef,
                                                     float* __restrict__ A, int ld, int co_off, RowMap rm) {
     const unsigned c4n = (unsigned)C >> 2;                   // C is a power of two here (train_step checks): mask / shift
     const unsigned i = blockIdx.x * 256u + threadIdx.x;      // rows * C / 4 < 2^32 (launcher)
@@ -824,28 +957,24 @@ __global__ __launch_bounds__(256) void k_tr_bn_relu(const float* __restrict__ Z,
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float v = (zz[j] - stats[2 * (c + j)]) * stats[2 * (c + j) + 1] * gamma[c + j] + beta[c + j];
-        o[j] = fmaxf(v, 0.f);
+        const float4 q = coef[c + j];
+        o[j] = fmaxf(fmaf(zz[j], q.x, q.y), 0.f);
     }
     *reinterpret_cast<float4*>(A + (size_t)map_row(rm, r) * ld + co_off + c) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// backward of BN + ReLU, pass 1: g = dA * (A > 0); part[blk][0][c] = sum g, part[blk][1][c] = sum g * zhat.
+// backward of BN + ReLU, pass 1: g = dA * (act > 0); part[blk][0][c] = sum g, part[blk][1][c] = sum g * zhat.
 // A workgroup owns a contiguous range of rows, a thread 4 channels (16-byte loads) of every (256 / (C / 4))-th row.
 __global__ __launch_bounds__(256) void k_tr_bn_bwd_reduce(const float* __restrict__ dA, int ld, int co_off, RowMap rm,
                                                           const float* __restrict__ Z, long rows, int C,
-                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ part) {
+                                                          const float4* __restrict__ coef, float* __restrict__ part) {
     __shared__ float4 s1[256], s2[256];
     const int tid = threadIdx.x;
     const int cq = C >> 2;
     const int q = tid % cq, rs = tid / cq, nrs = 256 / cq;
-    float mean[4], inv[4], ga[4], be[4];
+    float4 cf[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = 4 * q + j;
-        mean[j] = stats[2 * c]; inv[j] = stats[2 * c + 1]; ga[j] = gamma[c]; be[j] = beta[c];
-    }
+    for (int j = 0; j < 4; ++j) cf[j] = coef[4 * q + j];
     const long per = (rows + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * per, r1 = min(rows, r0 + per);
     float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
@@ -855,8 +984,8 @@ __global__ __launch_bounds__(256) void k_tr_bn_bwd_reduce(const float* __restric
         const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float zh = (zz[j] - mean[j]) * inv[j];
-            const float act = zh * ga[j] + be[j];
+            const float act = fmaf(zz[j], cf[j].x, cf[j].y);
+            const float zh = fmaf(zz[j], cf[j].z, cf[j].w);
             const float g = (act > 0.f) ? dd[j] : 0.f;
             a[j] += g; b[j] = fmaf(g, zh, b[j]);
         }
@@ -879,9 +1008,8 @@ __global__ __launch_bounds__(256) void k_tr_bn_bwd_reduce(const float* __restric
 // pass 2: dZ[r][c] = gamma * inv * (g - Sg / n - zhat * Sgz / n)   (sums[0] = Sg = d beta, sums[1] = Sgz = d gamma)
 __global__ __launch_bounds__(256) void k_tr_bn_bwd_apply(const float* __restrict__ dA, int ld, int co_off, RowMap rm,
                                                          const float* __restrict__ Z, long rows, int C,
-                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, const float* __restrict__ sums,
-                                                         float n_rows, float* __restrict__ dZ) {
+                                                         const float4* __restrict__ coef, const float* __restrict__ sums,
+                                                         float inv_n, float* __restrict__ dZ) {
     const unsigned c4n = (unsigned)C >> 2;                   // C is a power of two (train_step checks)
     const unsigned i = blockIdx.x * 256u + threadIdx.x;      // (row, channel quad)
     if ((long)i >= rows * (long)c4n) return;
@@ -889,17 +1017,106 @@ __global__ __launch_bounds__(256) void k_tr_bn_bwd_apply(const float* __restrict
     const long r = (long)(i / c4n);
     const float4 z4 = *reinterpret_cast<const float4*>(Z + (size_t)i * 4);
     const float4 d4 = *reinterpret_cast<const float4*>(dA + (size_t)map_row(rm, r) * ld + co_off + c);
+    const float4 m1 = *reinterpret_cast<const float4*>(sums + c), m2 = *reinterpret_cast<const float4*>(sums + C + c);
     const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float mm1[4] = {m1.x, m1.y, m1.z, m1.w}, mm2[4] = {m2.x, m2.y, m2.z, m2.w};
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float mean = stats[2 * (c + j)], inv = stats[2 * (c + j) + 1], ga = gamma[c + j];
-        const float zh = (zz[j] - mean) * inv;
-        const float act = zh * ga + beta[c + j];
+        const float4 q = coef[c + j];
+        const float act = fmaf(zz[j], q.x, q.y);
+        const float zh = fmaf(zz[j], q.z, q.w);
         const float g = (act > 0.f) ? dd[j] : 0.f;
-        o[j] = ga * inv * (g - sums[c + j] / n_rows - zh * (sums[C + c + j] / n_rows));
+        o[j] = q.x * (g - mm1[j] * inv_n - zh * (mm2[j] * inv_n));
     }
     *reinterpret_cast<float4*>(dZ + (size_t)i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// Backward of a stride-1 depthwise layer whose input is the BatchNorm + ReLU of the layer before it (Zp, coefp), one
+// pass instead of three (k_tr_dw_bwd_w, k_tr_dw_bwd_in and the k_tr_bn_bwd_reduce of the layer before): with the 3x3
+// window of dD around input pixel p in registers,
+//   dX[p][c]      = sum_t dD[p + 1 - d_t][c] * w[t][c]                  (stored: the layer before's dA)
+//   dw[t][c]     += x[p][c] * dD[p + 1 - d_t][c],  x = relu(zp * sc + sh)  (the same window, re-indexed by input pixel)
+//   Sg[c]        += g,  Sgz[c] += g * zhat,  g = dX * (x > 0)            (the layer before's BatchNorm-backward sums)
+// A workgroup owns a contiguous range of pixels, a thread 4 channels of every (256 / (C / 4))-th pixel; the 11 per-thread
+// sums meet in LDS three at a time and leave one partial row part[blk][11][C] (rows 0-8: dw taps, 9: Sg, 10: Sgz).
+__global__ __launch_bounds__(256) void k_tr_dw_bwd(const float* __restrict__ dD, const float* __restrict__ w,
+                                                   const float* __restrict__ Zp, const float4* __restrict__ coefp,
+                                                   float* __restrict__ dX, float* __restrict__ part, int B, int h, int wd, int C) {
+    __shared__ float4 sred[3 * 256];
+    const int tid = threadIdx.x;
+    const int cq = C >> 2;
+    const int q = tid % cq, ps = tid / cq, nps = 256 / cq;
+    const long npix = (long)B * h * wd;
+    const long per = (npix + gridDim.x - 1) / gridDim.x;
+    const long p0 = (long)blockIdx.x * per, p1 = min(npix, p0 + per);
+    float4 acc[11];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cf[j] = coefp[4 * q + j];
+    int x = 0, y = 0;
+    if (p0 + ps < p1) {
+        const unsigned up = (unsigned)(p0 + ps);             // pixel counts < 2^31 (launcher)
+        const unsigned qy = up / (unsigned)wd;
+        x = (int)(up - qy * (unsigned)wd);
+        y = (int)(qy % (unsigned)h);
+    }
+    for (long p = p0 + ps; p < p1; p += nps) {
+        const float4 z4 = *reinterpret_cast<const float4*>(Zp + (size_t)p * C + 4 * q);
+        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        float xa[4], zh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xa[j] = fmaxf(fmaf(zz[j], cf[j].x, cf[j].y), 0.f);
+            zh[j] = fmaf(zz[j], cf[j].z, cf[j].w);
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int oy = y + 1 - dy;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ox = x + 1 - dx;
+                if ((unsigned)oy < (unsigned)h && (unsigned)ox < (unsigned)wd) {
+                    // the output pixel (oy, ox) of the same frame: p + (1 - dy) * wd + (1 - dx)
+                    const float4 v = *reinterpret_cast<const float4*>(dD + (size_t)(p + (1 - dy) * wd + (1 - dx)) * C + 4 * q);
+                    const float4 k = *reinterpret_cast<const float4*>(w + (size_t)(dy * 3 + dx) * C + 4 * q);
+                    o.x = fmaf(v.x, k.x, o.x); o.y = fmaf(v.y, k.y, o.y); o.z = fmaf(v.z, k.z, o.z); o.w = fmaf(v.w, k.w, o.w);
+                    float4& a = acc[dy * 3 + dx];
+                    a.x = fmaf(xa[0], v.x, a.x); a.y = fmaf(xa[1], v.y, a.y); a.z = fmaf(xa[2], v.z, a.z); a.w = fmaf(xa[3], v.w, a.w);
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(dX + (size_t)p * C + 4 * q) = o;
+        const float g0 = (xa[0] > 0.f) ? o.x : 0.f, g1 = (xa[1] > 0.f) ? o.y : 0.f;
+        const float g2 = (xa[2] > 0.f) ? o.z : 0.f, g3 = (xa[3] > 0.f) ? o.w : 0.f;
+        acc[9].x += g0; acc[9].y += g1; acc[9].z += g2; acc[9].w += g3;
+        acc[10].x = fmaf(g0, zh[0], acc[10].x); acc[10].y = fmaf(g1, zh[1], acc[10].y);
+        acc[10].z = fmaf(g2, zh[2], acc[10].z); acc[10].w = fmaf(g3, zh[3], acc[10].w);
+        x += nps;
+        while (x >= wd) { x -= wd; if (++y == h) y = 0; }
+    }
+#pragma unroll
+    for (int t0 = 0; t0 < 12; t0 += 3) {
+        if (t0) __syncthreads();                         // the previous three sums have been read
+#pragma unroll
+        for (int t = 0; t < 3; ++t) if (t0 + t < 11) sred[t * 256 + tid] = acc[t0 + t];
+        __syncthreads();
+        if (ps == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (t0 + t >= 11) continue;
+                float4 v = acc[t0 + t];
+                for (int k = 1; k < nps; ++k) {
+                    const float4 u = sred[t * 256 + tid + k * cq];
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+                *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 11 + t0 + t) * C + 4 * q) = v;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1040,6 +1257,7 @@ __global__ __launch_bounds__(256) void k_tr_pfn_max(PfnT p, const float* __restr
             if (c >= C) continue;
             float best = -3.0e38f;
             int bi = -2;
+#pragma unroll 8
             for (int j = 0; j < n; ++j) {
                 const float v = fmaf(Y[(size_t)(row0 + j) * C + c], sc[q], sh[q]);
                 if (v > best) { best = v; bi = j; }
@@ -1153,7 +1371,7 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* _
             a[q] = (c < C) ? arg[((size_t)pi.b * p.max_voxels + pi.pid) * C + c] : -2;
             g[q] = (c < C && a[q] >= 0) ? dcanvas[((size_t)pi.b * ncanvas + cell) * C + c] : 0.f;
         }
-        for (int j = 0; j < pi.n; ++j) {
+        for (int j = 0; j < pi.n; ++j) {       // (unrolled by four: 280 -> 405 us at B=32, the registers cost more than the loads in flight gain)
             float f[10];
             pfn_row_features<CPL>(p, p.pts_sorted + (size_t)(pi.row0 + j) * p.F, pi.mx, pi.my, pi.mz, pi.cx, pi.cy, f);
 #pragma unroll
@@ -1274,49 +1492,59 @@ struct Lookup {
 
 unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
 
-// statistics from `nparts` partial rows [2][C * ntaps]
+// statistics from `nparts` partial rows [2][C * ntaps]; coef (with gamma, beta): the table the consumers of Z evaluate
 static void bn_finalize(const TrainCtx& cx, const float* part, int nparts, int C, float n_rows, const float* n_rows_dev,
-                        float momentum, int unbiased, float* stats, float* mmean, float* mvar, int ntaps) {
+                        float momentum, int unbiased, float* stats, float* mmean, float* mvar, int ntaps,
+                        const float* gamma = nullptr, const float* beta = nullptr, float4* coef = nullptr) {
     if ((long)nparts * ntaps >= 512)
         PP_LAUNCH("k_tr_bn_finalize", (k_tr_bn_finalize<64>), dim3((C + 3) / 4), dim3(256), 0, cx.stream, part, nparts, C, n_rows,
-                  n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps);
+                  n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps, gamma, beta, coef);
     else
         PP_LAUNCH("k_tr_bn_finalize", (k_tr_bn_finalize<16>), dim3((C + 15) / 16), dim3(256), 0, cx.stream, part, nparts, C, n_rows,
-                  n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps);
+                  n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps, gamma, beta, coef);
 }
 
-// TR_NPART partial rows of [2][C] -> sums[2][C] (and, when given, row 0 -> dup0[C], row 1 -> dup1[C])
-void col_reduce(const TrainCtx& cx, int C, float* sums, float* dup0 = nullptr, float* dup1 = nullptr) {
+// nparts partial rows of [2][C] (row stride pstride floats) -> sums[2][C] (and, when given, row 0 -> dup0[C], row 1 -> dup1[C])
+void col_reduce(const TrainCtx& cx, int C, float* sums, float* dup0 = nullptr, float* dup1 = nullptr,
+                const float* part = nullptr, long pstride = 0) {
     const long n = (long)2 * C;
-    PP_LAUNCH("k_tr_reduce", k_tr_reduce_cols, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, cx.stream, (const float*)cx.part,
-              TR_NPART, n, n, sums, 0L, 0, 0, 1.0f, dup0, dup1, C);
+    if (part == nullptr) { part = cx.part; pstride = n; }
+    PP_LAUNCH("k_tr_reduce", k_tr_reduce_cols, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, cx.stream, part,
+              TR_NPART, n, pstride, sums, 0L, 0, 0, 1.0f, dup0, dup1, C);
 }
 
-// BatchNorm (training) + ReLU over Z[rows][C] -> A (mapped rows), statistics kept in `stats`, moving stats updated
+// BatchNorm (training) statistics of Z[rows][C] -> stats + coefficient table, moving stats updated; with A != NULL the
+// activation relu(bn(Z)) is written too (mapped rows) -- only where somebody reads it as a tensor (the block-final
+// layers and the transposed convolutions); the in-block consumers evaluate it from Z and the table
 // stat_tiles > 0: the product that wrote Z left per-row-tile column sums in cx.stat_part ([stat_tiles][2][C * ntaps])
 void bn_relu_forward(const TrainCtx& cx, const float* Z, long rows, int C, const float* gamma, const float* beta,
-                     float* stats, float* sums, float* mmean, float* mvar, float momentum, float* A, int ld, int co_off,
+                     float* stats, float4* coef, float* mmean, float* mvar, float momentum, float* A, int ld, int co_off,
                      RowMap rm, int stat_tiles = 0, int ntaps = 1) {
     if (stat_tiles > 0) {
-        bn_finalize(cx, cx.stat_part, stat_tiles, C, (float)rows, nullptr, momentum, 1, stats, mmean, mvar, ntaps);
+        bn_finalize(cx, cx.stat_part, stat_tiles, C, (float)rows, nullptr, momentum, 1, stats, mmean, mvar, ntaps, gamma, beta, coef);
     } else {
         PP_LAUNCH("k_tr_colstats", k_tr_colstats, dim3(TR_NPART), dim3(256), 0, cx.stream, Z, rows, C, cx.part);
-        bn_finalize(cx, cx.part, TR_NPART, C, (float)rows, nullptr, momentum, 1, stats, mmean, mvar, 1);
+        bn_finalize(cx, cx.part, TR_NPART, C, (float)rows, nullptr, momentum, 1, stats, mmean, mvar, 1, gamma, beta, coef);
     }
-    (void)sums;
-    PP_LAUNCH("k_tr_bn_relu", k_tr_bn_relu, dim3(blocks_for(rows * (C / 4))), dim3(256), 0, cx.stream, Z, rows, C,
-              (const float*)stats, gamma, beta, A, ld, co_off, rm);
+    if (A != nullptr)
+        PP_LAUNCH("k_tr_bn_relu", k_tr_bn_relu, dim3(blocks_for(rows * (C / 4))), dim3(256), 0, cx.stream, Z, rows, C,
+                  (const float4*)coef, A, ld, co_off, rm);
 }
 
 // backward of the same: dA (mapped rows) -> dZ[rows][C]; d gamma, d beta written to the gradient buffer
+// sums_part != NULL: the sums of g and g * zhat already lie in TR_NPART partial rows (left by k_tr_dw_bwd)
 void bn_relu_backward(const TrainCtx& cx, const float* dA, int ld, int co_off, RowMap rm, const float* Z, long rows, int C,
-                      const float* stats, const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta,
-                      float* dZ) {
-    PP_LAUNCH("k_tr_bn_bwd_reduce", k_tr_bn_bwd_reduce, dim3(TR_NPART), dim3(256), 0, cx.stream, dA, ld, co_off, rm, Z, rows,
-              C, stats, gamma, beta, cx.part);
-    col_reduce(cx, C, sums, dbeta, dgamma);
+                      const float4* coef, float* sums, float* dgamma, float* dbeta, float* dZ,
+                      const float* sums_part = nullptr, long sums_pstride = 0) {
+    if (sums_part == nullptr) {
+        PP_LAUNCH("k_tr_bn_bwd_reduce", k_tr_bn_bwd_reduce, dim3(TR_NPART), dim3(256), 0, cx.stream, dA, ld, co_off, rm, Z, rows,
+                  C, coef, cx.part);
+        col_reduce(cx, C, sums, dbeta, dgamma);
+    } else {
+        col_reduce(cx, C, sums, dbeta, dgamma, sums_part, sums_pstride);
+    }
     PP_LAUNCH("k_tr_bn_bwd_apply", k_tr_bn_bwd_apply, dim3(blocks_for(rows * (C / 4))), dim3(256), 0, cx.stream, dA, ld, co_off, rm,
-              Z, rows, C, stats, gamma, beta, (const float*)sums, (float)rows, dZ);
+              Z, rows, C, coef, (const float*)sums, 1.0f / (float)rows, dZ);
 }
 
 // n_rows[0] = (sum of the frames' pillar counts) * T: the rows of the reference's padded [P, T, C] tensor
@@ -1360,7 +1588,7 @@ void pfn_backward(const TrainCtx& cx, const PfnT& p, const Lookup& L, const floa
 size_t train_part_floats(const TrainShape& s) {
     size_t m = (size_t)2 * 512;
     m = std::max(m, (size_t)10 * s.C);
-    for (const LayerDesc& L : s.layers) m = std::max(m, (size_t)9 * std::max(L.cin, L.cout));
+    for (const LayerDesc& L : s.layers) m = std::max(m, (size_t)11 * std::max(L.cin, L.cout));
     return (size_t)TR_NPART_MAX * m;
 }
 
@@ -1398,7 +1626,10 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
 
     const RowMap ident{1, 0, 0};
     const size_t HW = (size_t)s.head_h * s.head_w;
+    // cur: what the next layer reads -- a tensor (cur_coef == NULL: the canvas, a block-final activation) or the
+    // pre-BatchNorm map of an in-block layer with its coefficient table (the activation is evaluated by the reader)
     const float* cur = cx.canvas;
+    const float4* cur_coef = nullptr;
     int bi = 0, li = 0, co_off = 0;
     for (size_t i = 0; i < s.layers.size(); ++i) {
         const LayerDesc& l = s.layers[i];
@@ -1408,22 +1639,26 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
             const long rows = (long)B * l.out_h * l.out_w;
             PP_LAUNCH("k_tr_dw_fwd", k_tr_dw_fwd, dim3(blocks_for(rows * (l.cin / 4))), dim3(256), 0, cx.stream, cur,
                       L.p(pre + "/depthwise_kernel"), tb.D, (unsigned)(rows * (l.cin / 4)), l.in_h, l.in_w,
-                      make_div((unsigned)l.out_h), make_div((unsigned)l.out_w), make_div((unsigned)(l.cin / 4)), l.cin, l.stride);
+                      make_div((unsigned)l.out_h), make_div((unsigned)l.out_w), make_div((unsigned)(l.cin / 4)), l.cin, l.stride,
+                      cur_coef);
             tr_gemm(cx, tb.D, l.cin, 1, L.p(pre + "/pointwise_kernel"), l.cout, 1, tb.Z, l.cout, (int)rows, l.cout, l.cin,
                     nullptr, 0, 1, cx.stat_part);
-            bn_relu_forward(cx, tb.Z, rows, l.cout, L.p(pre + "/bn/gamma"), L.p(pre + "/bn/beta"), tb.stats, tb.sums,
+            // tb.A exists for the block-final layers only (the transposed convolution and the next block read it)
+            bn_relu_forward(cx, tb.Z, rows, l.cout, L.p(pre + "/bn/gamma"), L.p(pre + "/bn/beta"), tb.stats, tb.coef,
                             L.s(pre + "/bn/moving_mean"), L.s(pre + "/bn/moving_variance"), 0.99f, tb.A, l.cout, 0, ident,
                             g_last_stat_tiles, 1);
-            cur = tb.A;
+            if (tb.A != nullptr) { cur = tb.A; cur_coef = nullptr; }
+            else { cur = tb.Z; cur_coef = tb.coef; }
             ++li;
         } else if (l.kind == LAYER_DECONV) {
             const std::string pre = "rpn/deconv" + std::to_string(bi + 1);
             const long m = (long)B * l.in_h * l.in_w;
             const int N = l.k * l.k * l.cout;
+            if (cur_coef != nullptr) return PP_ERR_UNSUPPORTED;   // (a block always ends in a layer that keeps its activation)
             // Zs[m][tap * cout + co] = X[m][:] . K[tap][co][:]   (Keras Conv2DTranspose kernel [k, k, Cout, Cin])
             tr_gemm(cx, cur, l.cin, 1, L.p(pre + "/kernel"), 1, l.cin, tb.Z, N, (int)m, N, l.cin, nullptr, 0, 1, cx.stat_part);
             const RowMap rm{l.k, l.in_h, l.in_w};
-            bn_relu_forward(cx, tb.Z, m * l.k * l.k, l.cout, L.p(pre + "/bn/gamma"), L.p(pre + "/bn/beta"), tb.stats, tb.sums,
+            bn_relu_forward(cx, tb.Z, m * l.k * l.k, l.cout, L.p(pre + "/bn/gamma"), L.p(pre + "/bn/beta"), tb.stats, tb.coef,
                             L.s(pre + "/bn/moving_mean"), L.s(pre + "/bn/moving_variance"), 0.99f, cx.cat, s.CC, co_off, rm,
                             g_last_stat_tiles, l.k * l.k);
             co_off += l.cout;
@@ -1484,27 +1719,52 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
         const long m = (long)B * d.in_h * d.in_w;
         const int N = d.k * d.k * d.cout;
         const RowMap rm{d.k, d.in_h, d.in_w};
-        bn_relu_backward(cx, cx.dcat, s.CC, cat_off[b], rm, db.Z, m * d.k * d.k, d.cout, db.stats, L.p(dpre + "/bn/gamma"),
-                         L.p(dpre + "/bn/beta"), db.sums, L.g(dpre + "/bn/gamma"), L.g(dpre + "/bn/beta"), cx.dZ);
+        bn_relu_backward(cx, cx.dcat, s.CC, cat_off[b], rm, db.Z, m * d.k * d.k, d.cout, db.coef, db.sums,
+                         L.g(dpre + "/bn/gamma"), L.g(dpre + "/bn/beta"), cx.dZ);
         // dK[n][cin] = dZs^T . X     dX[m][cin] (+)= dZs . K
-        tr_gemm(cx, cx.dZ, 1, N, Xd, d.cin, 1, L.g(dpre + "/kernel"), d.cin, N, d.cin, (int)m, nullptr, 0,
-                wgrad_split(cx, N, d.cin, (int)m), nullptr, true);
         float* dAct = cx.lbuf[last].dA;
-        tr_gemm(cx, cx.dZ, N, 1, L.p(dpre + "/kernel"), d.cin, 1, dAct, d.cin, (int)m, d.cin, N, nullptr,
-                (b + 1 < nblocks) ? 1 : 0, 1);
+        tr_gemm_pair(cx,
+                     GemmCall{cx.dZ, 1, N, Xd, d.cin, 1, L.g(dpre + "/kernel"), d.cin, N, d.cin, (int)m, nullptr, 0,
+                              wgrad_split(cx, N, d.cin, (int)m), nullptr, true},
+                     GemmCall{cx.dZ, N, 1, L.p(dpre + "/kernel"), d.cin, 1, dAct, d.cin, (int)m, d.cin, N, nullptr,
+                              (b + 1 < nblocks) ? 1 : 0, dgrad_split((int)m, d.cin, N), nullptr, false});
+        // BatchNorm-backward sums of layer i left by the fused depthwise backward of layer i + 1 (NULL: not yet)
+        const float* sums_part = nullptr;
+        long sums_pstride = 0;
         for (int i = last; i >= first_of_block[b]; --i) {
             const LayerDesc& l = s.layers[i];
             const TrainLayerBuf& tb = cx.lbuf[i];
             const std::string pre = "rpn/block" + std::to_string(b + 1) + "/" + std::to_string(i - first_of_block[b]);
             const long rows = (long)B * l.out_h * l.out_w;
-            const float* X = (i == 0) ? cx.canvas : cx.lbuf[i - 1 - ((i == first_of_block[b] && b > 0) ? 1 : 0)].A;
-            bn_relu_backward(cx, tb.dA, l.cout, 0, ident, tb.Z, rows, l.cout, tb.stats, L.p(pre + "/bn/gamma"),
-                             L.p(pre + "/bn/beta"), tb.sums, L.g(pre + "/bn/gamma"), L.g(pre + "/bn/beta"), cx.dZ);
+            bn_relu_backward(cx, tb.dA, l.cout, 0, ident, tb.Z, rows, l.cout, tb.coef, tb.sums, L.g(pre + "/bn/gamma"),
+                             L.g(pre + "/bn/beta"), cx.dZ, sums_part, sums_pstride);
+            sums_part = nullptr;
             // dWp[cin][cout] = D^T . dZ      dD[rows][cin] = dZ . Wp^T
-            tr_gemm(cx, tb.D, 1, l.cin, cx.dZ, l.cout, 1, L.g(pre + "/pointwise_kernel"), l.cout, l.cin, l.cout, (int)rows,
-                    nullptr, 0, wgrad_split(cx, l.cin, l.cout, (int)rows), nullptr, true);
-            tr_gemm(cx, cx.dZ, l.cout, 1, L.p(pre + "/pointwise_kernel"), 1, l.cout, cx.dD, l.cin, (int)rows, l.cin, l.cout,
-                    nullptr, 0, 1);
+            tr_gemm_pair(cx,
+                         GemmCall{tb.D, 1, l.cin, cx.dZ, l.cout, 1, L.g(pre + "/pointwise_kernel"), l.cout, l.cin, l.cout,
+                                  (int)rows, nullptr, 0, wgrad_split(cx, l.cin, l.cout, (int)rows), nullptr, true},
+                         GemmCall{cx.dZ, l.cout, 1, L.p(pre + "/pointwise_kernel"), 1, l.cout, cx.dD, l.cin, (int)rows, l.cin,
+                                  l.cout, nullptr, 0, 1, nullptr, false});
+            const bool in_block = i > first_of_block[b];          // the input is the layer before's BatchNorm + ReLU of Z
+            if (in_block && l.stride == 1 && cx.lbuf[i - 1].A == nullptr) {
+                // one pass: depthwise kernel gradient, input gradient, and the layer before's BatchNorm-backward sums;
+                // partial rows [TR_NPART][11][cin] in a region of their own (the kernel-gradient rows are added by the
+                // step's deferred-reduction launch, the two sum rows by the layer before's col_reduce)
+                const TrainLayerBuf& pb = cx.lbuf[i - 1];
+                const long n = (long)11 * l.cin;
+                if (g_arena_used + (long)TR_NPART * n > cx.gemm_part_floats) return PP_ERR_UNSUPPORTED;
+                float* region = cx.gemm_part + g_arena_used;
+                PP_LAUNCH("k_tr_dw_bwd", k_tr_dw_bwd, dim3(TR_NPART), dim3(256), 0, cx.stream, (const float*)cx.dD,
+                          L.p(pre + "/depthwise_kernel"), (const float*)pb.Z, (const float4*)pb.coef, pb.dA, region, B, l.in_h,
+                          l.in_w, l.cin);
+                g_jobs.push_back(ReduceJob{region, L.g(pre + "/depthwise_kernel"), (long)9 * l.cin, n, 0L, TR_NPART, 0, 0, 1.0f});
+                g_arena_used += ((long)TR_NPART * n + 63) / 64 * 64;
+                sums_part = region + (long)9 * l.cin;
+                sums_pstride = n;
+                continue;
+            }
+            const float* X = (i == 0) ? cx.canvas : cx.lbuf[i - 1 - ((i == first_of_block[b] && b > 0) ? 1 : 0)].A;
+            if (X == nullptr) return PP_ERR_UNSUPPORTED;
             {   // partial rows [TR_NPART][9][cin] in a region of their own, added by the step's deferred-reduction launch
                 const long n = (long)9 * l.cin;
                 float* region = cx.part;
