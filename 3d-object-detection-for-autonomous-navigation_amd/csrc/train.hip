@@ -603,11 +603,11 @@ static void tr_gemm(const TrainCtx& cx, const GemmCall& c) {
         const long tall = (long)((M + 127) / 128) * ((N + 63) / 64) * ksplit;
         static int thr = -1;      // PP_TRAIN_TILE_THR: workgroups a launch must still have for the larger tile
         if (thr < 0) { const char* e = getenv("PP_TRAIN_TILE_THR"); thr = e ? atoi(e) : 512; }   // (measured at B=32: 512 2.15 ms of products, 256 2.22, 128 2.32)
-        if (N >= 128 && big >= thr) {
+        if (N >= 128 && M > 64 && big >= thr) {
             dim3 grid((N + 127) / 128, (M + 127) / 128, ksplit);
             if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
             launch_gemm2<2, 2, 32>(a2, akc, bkc, grid, cx.stream);
-        } else if (tall >= thr) {
+        } else if (M > 64 && tall >= thr) {      // (M <= 64: half of a 128-row tile would be zero rows -- the 64-channel weight gradients)
             dim3 grid((N + 63) / 64, (M + 127) / 128, ksplit);
             if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
             launch_gemm2<2, 1, 32>(a2, akc, bkc, grid, cx.stream);
