@@ -53,6 +53,7 @@ struct pp_engine {
     int in_buf = 0;                       // index of d_points / d_offsets
     hipStream_t copy_stream = nullptr;   // the device's shared upload stream (not owned by the handle)
     hipEvent_t ev_up = nullptr;           // recorded on the copy stream behind an asynchronous upload
+    hipEvent_t ev_tgt = nullptr;          // ... behind the labels / regression targets of a training step
     bool up_pending = false;              // the next pp_detect_async must wait for ev_up
     hipEvent_t ev_read[2] = {nullptr, nullptr};   // recorded on the main stream behind the pass that read buffer i
     float* d_points = nullptr;
@@ -127,7 +128,8 @@ struct pp_engine {
         // BUFFER: every upload flips the handle's input buffer (the kernels' point / offset pointers), so a single
         // graph would be re-captured on every optimizer step
         struct Graph {
-            hipGraphExec_t exec = nullptr;
+            hipGraphExec_t exec = nullptr;     // voxelise + forward
+            hipGraphExec_t exec_bwd = nullptr; // loss + backward (launched behind the target upload's event)
             int batch = -1, bucket = -1, zc = 0;
             const void *params = nullptr, *grads = nullptr, *state = nullptr;
             pp_loss_config loss;
@@ -761,6 +763,7 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
                 e->d_feed[i] = (const PpFeed*)dp;
             }
             if (st2 == PP_OK && hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
+            if (st2 == PP_OK && hipEventCreateWithFlags(&e->ev_tgt, hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
             for (int i = 0; i < 2 && st2 == PP_OK; ++i)
                 if (hipEventCreateWithFlags(&e->ev_read[i], hipEventDisableTiming) != hipSuccess) st2 = PP_ERR_HIP;
             if (st2 == PP_OK) {
@@ -815,13 +818,17 @@ int pp_destroy(pp_handle e) {
     graph_invalidate(e);
     for (void* p : e->allocs) (void)hipFree(p);
     for (void* p : e->wallocs) (void)hipFree(p);
-    if (e->train) for (auto& tg : e->train->graph) if (tg.exec) (void)hipGraphExecDestroy(tg.exec);
+    if (e->train) for (auto& tg : e->train->graph) {
+        if (tg.exec) (void)hipGraphExecDestroy(tg.exec);
+        if (tg.exec_bwd) (void)hipGraphExecDestroy(tg.exec_bwd);
+    }
     delete e->train;
     if (e->h_off_ring) (void)hipHostFree(e->h_off_ring);
     for (hipEvent_t ev : e->off_ev) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     for (PpFeed* f : e->h_feed) if (f) (void)hipHostFree(f);
     if (e->ev_up) (void)hipEventDestroy(e->ev_up);
+    if (e->ev_tgt) (void)hipEventDestroy(e->ev_tgt);
     for (hipEvent_t ev : e->ev_read) if (ev) (void)hipEventDestroy(ev);
     if (e->d_voxels) (void)hipFree(e->d_voxels);
     if (e->d_numpts) (void)hipFree(e->d_numpts);
@@ -1785,8 +1792,18 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
         e->up_pending = false;
     }
     prof_reset(e);
-    HIPCHK(e, hipMemcpyAsync(e->d_loss_labels, labels, (size_t)batch * e->A * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->d_loss_regt, reg_targets, (size_t)batch * e->A * 7 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    // labels and regression targets travel on the copy stream (behind the points, if their upload is still queued
+    // there) while voxeliser and forward pass run: the loss kernel is the first reader, the second half of the step
+    // waits for ev_tgt.  (The previous step has been synchronised before it returned: nobody still reads the buffers.)
+    // Issued AFTER the first half has been launched: a pageable source makes hipMemcpyAsync block the host, and the
+    // GPU should be busy with the forward pass by then.
+    auto upload_targets = [&]() -> int {
+        HIPCHK(e, hipMemcpyAsync(e->d_loss_labels, labels, (size_t)batch * e->A * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
+        HIPCHK(e, hipMemcpyAsync(e->d_loss_regt, reg_targets, (size_t)batch * e->A * 7 * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
+        HIPCHK(e, hipEventRecord(e->ev_tgt, e->copy_stream));
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_tgt, 0));
+        return PP_OK;
+    };
     pp_engine::TrainState* t = e->train;
     TrainCtx& cx = t->cx;
     cx.stream = e->stream;
@@ -1795,45 +1812,62 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
     cx.head = e->d_head; cx.dhead = e->d_head_grad;
     LossParams lp;
     fill_loss_params(e, lc, batch, lp);
-    auto enqueue = [&](int max_n) -> int {
-        int r = run_voxelize(e, batch, max_n);
-        if (r) return r;
-        return train_step(cx, t->shape, t->layout, params_dev, grads_dev, state_dev, batch, lp);
+    // the step in two halves: 1 = voxelise + forward, 2 = loss + backward
+    auto enqueue = [&](int max_n, int phase) -> int {
+        if (phase & 1) {
+            int r = run_voxelize(e, batch, max_n);
+            if (r) return r;
+        }
+        return train_step(cx, t->shape, t->layout, params_dev, grads_dev, state_dev, batch, lp, phase);
     };
     bool launched = false;
     if (e->prof <= 0 && t->graph_state == 0 && graphs_enabled()) {
         const int bucket = graph_bucket(e, e->cur_max_n);
         pp_engine::TrainState::Graph& tg = t->graph[e->in_buf & 1];
-        const bool hit = tg.exec != nullptr && tg.batch == batch && tg.bucket == bucket && tg.zc == (e->zc ? 1 : 0) &&
-                         tg.params == params_dev && tg.grads == grads_dev && tg.state == state_dev &&
-                         memcmp(&tg.loss, lc, sizeof(pp_loss_config)) == 0;
+        const bool hit = tg.exec != nullptr && tg.exec_bwd != nullptr && tg.batch == batch && tg.bucket == bucket &&
+                         tg.zc == (e->zc ? 1 : 0) && tg.params == params_dev && tg.grads == grads_dev &&
+                         tg.state == state_dev && memcmp(&tg.loss, lc, sizeof(pp_loss_config)) == 0;
         if (!hit) {
-            if (tg.exec) {
+            if (tg.exec || tg.exec_bwd) {
                 HIPCHK(e, hipStreamSynchronize(e->stream));
-                (void)hipGraphExecDestroy(tg.exec);
-                tg.exec = nullptr;
+                if (tg.exec) (void)hipGraphExecDestroy(tg.exec);
+                if (tg.exec_bwd) (void)hipGraphExecDestroy(tg.exec_bwd);
+                tg.exec = tg.exec_bwd = nullptr;
             }
-            hipGraph_t g = nullptr;
-            bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            st = ok ? enqueue(bucket) : PP_ERR_HIP;
-            if (ok && hipStreamEndCapture(e->stream, &g) != hipSuccess) { ok = false; g = nullptr; }
-            if (ok && st == PP_ERR_UNSUPPORTED) {
+            bool all_ok = true;
+            for (int phase = 1; phase <= 2 && all_ok; ++phase) {
+                hipGraph_t g = nullptr;
+                bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                st = ok ? enqueue(bucket, phase) : PP_ERR_HIP;
+                if (ok && hipStreamEndCapture(e->stream, &g) != hipSuccess) { ok = false; g = nullptr; }
+                if (ok && st == PP_ERR_UNSUPPORTED) {
+                    if (g) (void)hipGraphDestroy(g);
+                    if (tg.exec) { (void)hipGraphExecDestroy(tg.exec); tg.exec = nullptr; }
+                    return fail(e, st, "pp_train_step: configuration not supported by the training kernels");
+                }
+                hipGraphExec_t* slot = (phase == 1) ? &tg.exec : &tg.exec_bwd;
+                if (!(ok && st == PP_OK && g != nullptr && hipGraphInstantiate(slot, g, nullptr, nullptr, 0) == hipSuccess)) {
+                    *slot = nullptr;
+                    all_ok = false;
+                }
                 if (g) (void)hipGraphDestroy(g);
-                return fail(e, st, "pp_train_step: configuration not supported by the training kernels");
             }
-            if (ok && st == PP_OK && g != nullptr && hipGraphInstantiate(&tg.exec, g, nullptr, nullptr, 0) == hipSuccess) {
+            if (all_ok) {
                 tg.batch = batch; tg.bucket = bucket; tg.zc = e->zc ? 1 : 0;
                 tg.params = params_dev; tg.grads = grads_dev; tg.state = state_dev; tg.loss = *lc;
                 ++t->n_captures;
             } else {
-                tg.exec = nullptr;
+                if (tg.exec) (void)hipGraphExecDestroy(tg.exec);
+                if (tg.exec_bwd) (void)hipGraphExecDestroy(tg.exec_bwd);
+                tg.exec = tg.exec_bwd = nullptr;
                 t->graph_state = -1;
                 (void)hipGetLastError();
             }
-            if (g) (void)hipGraphDestroy(g);
         }
-        if (tg.exec != nullptr) {
+        if (tg.exec != nullptr && tg.exec_bwd != nullptr) {
             HIPCHK(e, hipGraphLaunch(tg.exec, e->stream));
+            if ((st = upload_targets())) return st;
+            HIPCHK(e, hipGraphLaunch(tg.exec_bwd, e->stream));
             ++t->n_replays;
             launched = true;
             st = PP_OK;
@@ -1841,7 +1875,9 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
     }
     if (!launched) {
         ProfScope ps(e, nullptr);
-        st = enqueue(e->cur_max_n);
+        st = enqueue(e->cur_max_n, 1);
+        if (st == PP_OK) st = upload_targets();
+        if (st == PP_OK) st = enqueue(e->cur_max_n, 2);
     }
     if (st) return fail(e, st, "pp_train_step: configuration not supported by the training kernels");
     HIPCHK(e, hipGetLastError());

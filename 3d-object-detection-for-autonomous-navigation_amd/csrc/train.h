@@ -72,4 +72,4 @@ std::vector<TrainEntry> train_layout(const TrainShape& s, int64_t* n_params, int
 size_t train_part_floats(const TrainShape& s);
 // forward (training mode) + loss + backward for `batch` resident, voxelised frames; grads overwritten, state updated
 int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainEntry>& layout, const float* params,
-               float* grads, float* state, int batch, const LossParams& loss);
+               float* grads, float* state, int batch, const LossParams& loss, int phase = 3);

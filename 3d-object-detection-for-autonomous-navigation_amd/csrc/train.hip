@@ -1593,7 +1593,10 @@ size_t train_part_floats(const TrainShape& s) {
 }
 
 int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainEntry>& layout, const float* params,
-               float* grads, float* state, int batch, const LossParams& loss_in) {
+               float* grads, float* state, int batch, const LossParams& loss_in, int phase) {
+    // phase bit 1: forward (PFN .. head maps); bit 2: loss + backward.  pp_train_step enqueues the two halves one after
+    // the other with a wait for the target upload in between (the labels / regression targets travel on the copy
+    // stream while the forward pass runs)
     Lookup L{layout, params, grads, state};
     const int B = batch;
     g_jobs.clear();
@@ -1617,6 +1620,11 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
     p.pts_sorted = cx.pts_sorted; p.offsets = cx.offsets; p.pillar_start = cx.pillar_start; p.pillar_cell = cx.pillar_cell;
     p.npillars = cx.npillars; p.W = L.p("pfn/dense/kernel"); p.pprefix = cx.pfn_prefix;
     const int cpl = (s.C + 63) / 64;
+    const RowMap ident{1, 0, 0};
+    const size_t HW = (size_t)s.head_h * s.head_w;
+    const int nb = s.napl * 7, nc = s.napl * s.ncls, nd = s.use_dir ? s.napl * 2 : 0;
+    const long px = (long)B * HW;
+    if (phase & 1) {
     if (cpl == 1) pfn_forward<1>(cx, p, L);
     else if (cpl == 2) pfn_forward<2>(cx, p, L);
     else pfn_forward<4>(cx, p, L);
@@ -1624,8 +1632,6 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
     PP_LAUNCH("k_tr_scatter", k_tr_scatter, dim3(blocks_for((long)B * ncanvas * (s.C / 4))), dim3(256), 0, cx.stream, cx.cellmap,
               (const float*)cx.pfn_feat, cx.canvas, B, s.nz, ncanvas, s.C, s.max_voxels);
 
-    const RowMap ident{1, 0, 0};
-    const size_t HW = (size_t)s.head_h * s.head_w;
     // cur: what the next layer reads -- a tensor (cur_coef == NULL: the canvas, a block-final activation) or the
     // pre-BatchNorm map of an in-block layer with its coefficient table (the activation is evaluated by the reader)
     const float* cur = cx.canvas;
@@ -1666,14 +1672,14 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
         }
     }
     // heads: head[px][32] = cat[px][CC] . Wh[CC][32] + bias
-    const int nb = s.napl * 7, nc = s.napl * s.ncls, nd = s.use_dir ? s.napl * 2 : 0;
     const float* kd = nd ? L.p("rpn/conv_dir_cls/kernel") : L.p("rpn/conv_box/kernel");
     const float* bd = nd ? L.p("rpn/conv_dir_cls/bias") : L.p("rpn/conv_box/bias");
     PP_LAUNCH("k_tr_pack_heads", k_tr_pack_heads, dim3(blocks_for((long)s.CC * PP_HEAD_COLS)), dim3(256), 0, cx.stream,
               L.p("rpn/conv_box/kernel"), L.p("rpn/conv_cls/kernel"), kd, L.p("rpn/conv_box/bias"), L.p("rpn/conv_cls/bias"), bd,
               s.CC, nb, nc, nd, cx.head_w, cx.head_b);
-    const long px = (long)B * HW;
     tr_gemm(cx, cx.cat, s.CC, 1, cx.head_w, PP_HEAD_COLS, 1, cx.head, PP_HEAD_COLS, (int)px, PP_HEAD_COLS, s.CC, cx.head_b, 0, 1);
+    }   // forward
+    if (!(phase & 2)) return PP_OK;
 
     // ---------------- loss + gradient at the head maps ----------------
     LossParams lp = loss_in;
