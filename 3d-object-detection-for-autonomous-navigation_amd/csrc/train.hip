@@ -597,12 +597,15 @@ static void tr_gemm(const TrainCtx& cx, const GemmCall& c) {
         ksplit = (K + kper - 1) / kper;
         g.kper = kper;
         TGemm2 a2{g, (ksplit == 1) ? c.stat_part : nullptr, 0, 0, ksplit};
-        // big tiles when they still fill the chip (two workgroups per CU), small ones otherwise; 64-column layers keep
-        // 128 rows per workgroup (two accumulator tiles per wave share every weight fragment)
+        // 64 x 64 tiles everywhere by default: five workgroups per CU (88 VGPRs, 30 KB of LDS) whose load -> split ->
+        // LDS -> MFMA phases overlap each other's; the 128-row / 128-column instantiations (two or four accumulator
+        // tiles per wave sharing their fragments, two / three workgroups per CU) stay selectable for measurements.
+        // PP_TRAIN_TILE_THR = workgroups a launch must still have for a larger tile; products of a B=32 step:
+        // 128 -> 2.32 ms, 256 -> 2.22, 512 -> 2.16, 1024 -> 2.13, 2048 -> 2.05, 4096 -> 2.01, never -> 2.00
         const long big = (long)((M + 127) / 128) * ((N + 127) / 128) * ksplit;
         const long tall = (long)((M + 127) / 128) * ((N + 63) / 64) * ksplit;
-        static int thr = -1;      // PP_TRAIN_TILE_THR: workgroups a launch must still have for the larger tile
-        if (thr < 0) { const char* e = getenv("PP_TRAIN_TILE_THR"); thr = e ? atoi(e) : 512; }   // (measured at B=32: 512 2.15 ms of products, 256 2.22, 128 2.32)
+        static long thr = -1;
+        if (thr < 0) { const char* e = getenv("PP_TRAIN_TILE_THR"); thr = e ? atol(e) : (1l << 40); }
         if (N >= 128 && M > 64 && big >= thr) {
             dim3 grid((N + 127) / 128, (M + 127) / 128, ksplit);
             if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
