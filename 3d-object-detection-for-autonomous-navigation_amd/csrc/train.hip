@@ -439,6 +439,28 @@ __global__ __launch_bounds__(256) void k_tr_reduce_cols(const float* __restrict_
     }
 }
 
+// ... and a whole workgroup per output when there are very many partial rows (large per-GPU batches)
+__global__ __launch_bounds__(256) void k_tr_reduce_cols_wg(const float* __restrict__ part, int nparts, long n, long pstride,
+                                                           float* __restrict__ out, long ldo, int ncols, int accumulate,
+                                                           float scale, float* __restrict__ dup0, float* __restrict__ dup1,
+                                                           int dup_split) {
+    __shared__ float sw[4];
+    const long i = blockIdx.x;
+    float s = 0.f;
+    for (int p = threadIdx.x; p < nparts; p += 256) s += part[(size_t)p * pstride + i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+    reduce_store(s, i, out, ldo, ncols, accumulate, scale);
+    if (dup0 != nullptr) {
+        if (i < dup_split) dup0[i] = s * scale;
+        else dup1[i - dup_split] = s * scale;
+    }
+}
+
 // one reduction launch: the shape follows the number of outputs
 static void tr_reduce(hipStream_t st, const float* part, int nparts, long n, long pstride, float* out, long ldo, int ncols,
                       int accumulate, float scale) {
@@ -890,7 +912,7 @@ __global__ __launch_bounds__(256) void k_tr_colstats(const float* __restrict__ Z
 // with the biased batch variance; moving statistics updated in place as Keras does
 // (ntaps > 1: the partial rows are [2][ntaps * C] -- a transposed convolution's GEMM columns, tap-major -- and a
 // channel's statistics run over all its taps)
-// LPC lanes share a channel (16: a handful of partial rows; 64: the many row tiles of a large batch)
+// LPC lanes share a channel (16: a handful of partial rows; 64 / 256: the many row tiles of a large batch)
 template <int LPC>
 __global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict__ part, int nparts, int C, float n_rows_arg,
                                                         const float* __restrict__ n_rows_dev, float momentum,
@@ -910,7 +932,14 @@ __global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict_
             }
     }
 #pragma unroll
-    for (int off = LPC / 2; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    for (int off = (LPC > 64 ? 64 : LPC) / 2; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if (LPC > 64) {                                       // a whole workgroup per channel: the four wave sums in order
+        __shared__ float sw[2][4];
+        if ((threadIdx.x & 63) == 0) { sw[0][threadIdx.x >> 6] = s1; sw[1][threadIdx.x >> 6] = s2; }
+        __syncthreads();
+        s1 = ((sw[0][0] + sw[0][1]) + sw[0][2]) + sw[0][3];
+        s2 = ((sw[1][0] + sw[1][1]) + sw[1][2]) + sw[1][3];
+    }
     if (c >= C || l != 0) return;
     const float n_rows = fmaxf((n_rows_dev != nullptr) ? *n_rows_dev : n_rows_arg, 1.f);   // PFN: P * T, known on the device only
     const float mean = s1 / n_rows;
@@ -1499,7 +1528,10 @@ unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
 static void bn_finalize(const TrainCtx& cx, const float* part, int nparts, int C, float n_rows, const float* n_rows_dev,
                         float momentum, int unbiased, float* stats, float* mmean, float* mvar, int ntaps,
                         const float* gamma = nullptr, const float* beta = nullptr, float4* coef = nullptr) {
-    if ((long)nparts * ntaps >= 512)
+    if ((long)nparts * ntaps >= 2048)
+        PP_LAUNCH("k_tr_bn_finalize", (k_tr_bn_finalize<256>), dim3(C), dim3(256), 0, cx.stream, part, nparts, C, n_rows,
+                  n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps, gamma, beta, coef);
+    else if ((long)nparts * ntaps >= 512)
         PP_LAUNCH("k_tr_bn_finalize", (k_tr_bn_finalize<64>), dim3((C + 3) / 4), dim3(256), 0, cx.stream, part, nparts, C, n_rows,
                   n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps, gamma, beta, coef);
     else
@@ -1509,11 +1541,15 @@ static void bn_finalize(const TrainCtx& cx, const float* part, int nparts, int C
 
 // nparts partial rows of [2][C] (row stride pstride floats) -> sums[2][C] (and, when given, row 0 -> dup0[C], row 1 -> dup1[C])
 void col_reduce(const TrainCtx& cx, int C, float* sums, float* dup0 = nullptr, float* dup1 = nullptr,
-                const float* part = nullptr, long pstride = 0) {
+                const float* part = nullptr, long pstride = 0, int nparts = 0) {
     const long n = (long)2 * C;
-    if (part == nullptr) { part = cx.part; pstride = n; }
-    PP_LAUNCH("k_tr_reduce", k_tr_reduce_cols, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, cx.stream, part,
-              TR_NPART, n, pstride, sums, 0L, 0, 0, 1.0f, dup0, dup1, C);
+    if (part == nullptr) { part = cx.part; pstride = n; nparts = TR_NPART; }
+    if (nparts >= 1024)
+        PP_LAUNCH("k_tr_reduce", k_tr_reduce_cols_wg, dim3((unsigned)n), dim3(256), 0, cx.stream, part,
+                  nparts, n, pstride, sums, 0L, 0, 0, 1.0f, dup0, dup1, C);
+    else
+        PP_LAUNCH("k_tr_reduce", k_tr_reduce_cols, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, cx.stream, part,
+                  nparts, n, pstride, sums, 0L, 0, 0, 1.0f, dup0, dup1, C);
 }
 
 // BatchNorm (training) statistics of Z[rows][C] -> stats + coefficient table, moving stats updated; with A != NULL the
@@ -1538,13 +1574,13 @@ void bn_relu_forward(const TrainCtx& cx, const float* Z, long rows, int C, const
 // sums_part != NULL: the sums of g and g * zhat already lie in TR_NPART partial rows (left by k_tr_dw_bwd)
 void bn_relu_backward(const TrainCtx& cx, const float* dA, int ld, int co_off, RowMap rm, const float* Z, long rows, int C,
                       const float4* coef, float* sums, float* dgamma, float* dbeta, float* dZ,
-                      const float* sums_part = nullptr, long sums_pstride = 0) {
+                      const float* sums_part = nullptr, long sums_pstride = 0, int sums_nparts = 0) {
     if (sums_part == nullptr) {
         PP_LAUNCH("k_tr_bn_bwd_reduce", k_tr_bn_bwd_reduce, dim3(TR_NPART), dim3(256), 0, cx.stream, dA, ld, co_off, rm, Z, rows,
                   C, coef, cx.part);
         col_reduce(cx, C, sums, dbeta, dgamma);
     } else {
-        col_reduce(cx, C, sums, dbeta, dgamma, sums_part, sums_pstride);
+        col_reduce(cx, C, sums, dbeta, dgamma, sums_part, sums_pstride, sums_nparts);
     }
     PP_LAUNCH("k_tr_bn_bwd_apply", k_tr_bn_bwd_apply, dim3(blocks_for(rows * (C / 4))), dim3(256), 0, cx.stream, dA, ld, co_off, rm,
               Z, rows, C, coef, (const float*)sums, 1.0f / (float)rows, dZ);
@@ -1578,11 +1614,13 @@ void pfn_backward(const TrainCtx& cx, const PfnT& p, const Lookup& L, const floa
     PP_LAUNCH("k_tr_pfn_bwd_reduce", (k_tr_pfn_bwd_reduce<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p,
               (const float*)cx.pfn_y, (const float*)cx.pfn_stats, (const int*)cx.pfn_arg, dcanvas, cx.part);
     col_reduce(cx, p.C, cx.pfn_sums, L.g("pfn/bn/beta"), L.g("pfn/bn/gamma"));
-    PP_LAUNCH("k_tr_pfn_bwd_apply", (k_tr_pfn_bwd_apply<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, (const float*)cx.pfn_y,
+    // (104 - 145 VGPRs: four resident workgroups per CU at most -- one round of workgroups, no quarter-filled second one)
+    const int nblk = std::min(TR_NPART, CPL == 4 ? 768 : 1024);
+    PP_LAUNCH("k_tr_pfn_bwd_apply", (k_tr_pfn_bwd_apply<CPL>), dim3(nblk), dim3(256), 0, cx.stream, p, (const float*)cx.pfn_y,
               (const float*)cx.pfn_stats, L.p("pfn/bn/gamma"), (const int*)cx.pfn_arg, dcanvas, (const float*)cx.pfn_sums,
               (const float*)cx.pfn_nrows, cx.part);
     const long n = (long)p.FA * p.C;
-    tr_reduce(cx.stream, (const float*)cx.part, TR_NPART, n, n,
+    tr_reduce(cx.stream, (const float*)cx.part, nblk, n, n,
               L.g("pfn/dense/kernel"), 0L, 0, 0, 1.0f);
 }
 
@@ -1740,13 +1778,14 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
         // BatchNorm-backward sums of layer i left by the fused depthwise backward of layer i + 1 (NULL: not yet)
         const float* sums_part = nullptr;
         long sums_pstride = 0;
+        int sums_nparts = 0;
         for (int i = last; i >= first_of_block[b]; --i) {
             const LayerDesc& l = s.layers[i];
             const TrainLayerBuf& tb = cx.lbuf[i];
             const std::string pre = "rpn/block" + std::to_string(b + 1) + "/" + std::to_string(i - first_of_block[b]);
             const long rows = (long)B * l.out_h * l.out_w;
             bn_relu_backward(cx, tb.dA, l.cout, 0, ident, tb.Z, rows, l.cout, tb.coef, tb.sums, L.g(pre + "/bn/gamma"),
-                             L.g(pre + "/bn/beta"), cx.dZ, sums_part, sums_pstride);
+                             L.g(pre + "/bn/beta"), cx.dZ, sums_part, sums_pstride, sums_nparts);
             sums_part = nullptr;
             // dWp[cin][cout] = D^T . dZ      dD[rows][cin] = dZ . Wp^T
             tr_gemm_pair(cx,
@@ -1761,15 +1800,19 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                 // step's deferred-reduction launch, the two sum rows by the layer before's col_reduce)
                 const TrainLayerBuf& pb = cx.lbuf[i - 1];
                 const long n = (long)11 * l.cin;
-                if (g_arena_used + (long)TR_NPART * n > cx.gemm_part_floats) return PP_ERR_UNSUPPORTED;
+                // at most one resident round of workgroups (118 VGPRs: four waves per SIMD = four workgroups per CU);
+                // 1 280 workgroups on 1 024 slots ran a quarter-filled second round
+                const int nblk = std::min(TR_NPART, 1024);
+                if (g_arena_used + (long)nblk * n > cx.gemm_part_floats) return PP_ERR_UNSUPPORTED;
                 float* region = cx.gemm_part + g_arena_used;
-                PP_LAUNCH("k_tr_dw_bwd", k_tr_dw_bwd, dim3(TR_NPART), dim3(256), 0, cx.stream, (const float*)cx.dD,
+                PP_LAUNCH("k_tr_dw_bwd", k_tr_dw_bwd, dim3(nblk), dim3(256), 0, cx.stream, (const float*)cx.dD,
                           L.p(pre + "/depthwise_kernel"), (const float*)pb.Z, (const float4*)pb.coef, pb.dA, region, B, l.in_h,
                           l.in_w, l.cin);
-                g_jobs.push_back(ReduceJob{region, L.g(pre + "/depthwise_kernel"), (long)9 * l.cin, n, 0L, TR_NPART, 0, 0, 1.0f});
-                g_arena_used += ((long)TR_NPART * n + 63) / 64 * 64;
+                g_jobs.push_back(ReduceJob{region, L.g(pre + "/depthwise_kernel"), (long)9 * l.cin, n, 0L, nblk, 0, 0, 1.0f});
+                g_arena_used += ((long)nblk * n + 63) / 64 * 64;
                 sums_part = region + (long)9 * l.cin;
                 sums_pstride = n;
+                sums_nparts = nblk;
                 continue;
             }
             const float* X = (i == 0) ? cx.canvas : cx.lbuf[i - 1 - ((i == first_of_block[b] && b > 0) ? 1 : 0)].A;
