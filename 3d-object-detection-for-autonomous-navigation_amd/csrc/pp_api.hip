@@ -1667,7 +1667,6 @@ int train_buffers(pp_engine* e) {
     const size_t B = (size_t)e->B, HW = (size_t)s.head_h * s.head_w;
     int st = PP_OK;
     auto A1 = [&](int r) { if (st == PP_OK) st = r; };
-    A1(dalloc(e, &cx.pfn_y, B * e->NMAX * s.C));
     A1(dalloc(e, &cx.pfn_feat, B * s.max_voxels * s.C));
     A1(dalloc(e, &cx.pfn_arg, B * s.max_voxels * s.C));
     A1(dalloc(e, &cx.pfn_stats, (size_t)2 * s.C));

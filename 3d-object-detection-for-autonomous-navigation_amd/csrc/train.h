@@ -41,7 +41,6 @@ struct TrainCtx {
     const int* npillars;
     const int* cellmap;
     // PFN
-    float* pfn_y;        // [sum N][C]
     float* pfn_feat;     // [B * max_voxels][C]
     int* pfn_arg;        // [B * max_voxels][C]
     float* pfn_stats;    // [C][2]

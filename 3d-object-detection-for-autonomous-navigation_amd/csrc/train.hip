@@ -1174,38 +1174,57 @@ __device__ __forceinline__ void pillar_of(const PfnT& p, int gp, int& bcur, int&
     pid = gp - p.pprefix[bcur];
 }
 
-// the decorated features of point j of a pillar (wave-uniform inputs): raw F | xyz - mean | xy - centre | [norm]
-// (f[0..9], unused tail zero; written with selects so that f stays in registers)
-template <int CPL>
-__device__ __forceinline__ void pfn_row_features(const PfnT& p, const float* q, float mx, float my, float mz, float cx,
-                                                 float cy, float (&f)[10]) {
-    const bool f4 = p.F > 3;
-    const float x = q[0], y = q[1], z = q[2], it = f4 ? q[3] : 0.f;
-    const float e0 = x - mx, e1 = y - my, e2 = z - mz, e3 = x - cx, e4 = y - cy;
-    const float e5 = p.with_distance ? sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z))) : 0.f;
-    f[0] = x; f[1] = y; f[2] = z;
-    f[3] = f4 ? it : e0; f[4] = f4 ? e0 : e1; f[5] = f4 ? e1 : e2; f[6] = f4 ? e2 : e3; f[7] = f4 ? e3 : e4;
-    f[8] = f4 ? e4 : e5; f[9] = f4 ? e5 : 0.f;
-}
-
 __device__ __forceinline__ float wave_sum_f(float x) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
     return x;
 }
 
-// pillar geometry shared by the PFN kernels: frame, pillar id -> row range, mean, centre
-struct PillarInfo { int b, pid, n; long row0; float mx, my, mz, cx, cy; };
-__device__ __forceinline__ bool pillar_info(const PfnT& p, int gp, int lane, PillarInfo& o, int& bcur) {
+// ---- round 3: the PFN kernels without the pre-BatchNorm tensor Y[sum N][C] ----
+// A pillar row's Dense output is ten FMAs per channel; the tensor Y (268 MB at B=32) cost a write and three reads, and
+// every kernel walked a pillar's rows one dependent load at a time.  Now a wave loads its pillar's points ONCE, 64 at
+// a time, one per lane (coalesced), broadcasts them with v_readlane and RECOMPUTES y = features . W wherever it is
+// needed (the same FMA chain everywhere: the statistics, the max, the gradients all see bit-identical values); no
+// memory access inside the per-point loop.
+struct PtsBatch { float x, y, z, it; };
+__device__ __forceinline__ PtsBatch pfn_load_batch(const PfnT& p, long row0, int n, int j0, int lane) {
+    PtsBatch r{0.f, 0.f, 0.f, 0.f};
+    const int j = j0 + lane;
+    if (j < n) {
+        const float* q = p.pts_sorted + (size_t)(row0 + j) * p.F;
+        if (p.F > 3) { const float4 v = *reinterpret_cast<const float4*>(q); r.x = v.x; r.y = v.y; r.z = v.z; r.it = v.w; }
+        else { r.x = q[0]; r.y = q[1]; r.z = q[2]; }
+    }
+    return r;
+}
+__device__ __forceinline__ float pfn_bcast(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// the decorated features of a pillar row from wave-uniform coordinates: raw F | xyz - mean | xy - centre | [norm]
+// (f[0..9], unused tail zero; written with selects so that f stays in registers)
+__device__ __forceinline__ void pfn_features(const PfnT& p, float x, float y, float z, float it, float mx, float my, float mz,
+                                             float cx, float cy, float (&f)[10]) {
+    const bool f4 = p.F > 3;
+    const float e0 = x - mx, e1 = y - my, e2 = z - mz, e3 = x - cx, e4 = y - cy;
+    const float e5 = p.with_distance ? sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z))) : 0.f;
+    f[0] = x; f[1] = y; f[2] = z;
+    f[3] = f4 ? it : e0; f[4] = f4 ? e0 : e1; f[5] = f4 ? e1 : e2; f[6] = f4 ? e2 : e3; f[7] = f4 ? e3 : e4;
+    f[8] = f4 ? e4 : e5; f[9] = f4 ? e5 : 0.f;
+}
+// pillar geometry with the first 64 points already in the lanes: frame, row range, mean (lane-strided partial sums,
+// then the xor tree), centre
+struct PillarHead { int b, pid, n; long row0; float mx, my, mz, cx, cy; PtsBatch first; };
+__device__ __forceinline__ void pillar_head(const PfnT& p, int gp, int lane, int& bcur, PillarHead& o) {
     pillar_of(p, gp, bcur, o.b, o.pid);
     const int* ps = p.pillar_start + (size_t)o.b * (p.max_voxels + 1);
     const int start = ps[o.pid];
     o.n = min(ps[o.pid + 1] - start, p.T);
     o.row0 = (long)p.offsets[o.b] + start;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int j = lane; j < o.n; j += 64) {
-        const float* q = p.pts_sorted + (size_t)(o.row0 + j) * p.F;
-        sx += q[0]; sy += q[1]; sz += q[2];
+    o.first = pfn_load_batch(p, o.row0, o.n, 0, lane);
+    float sx = o.first.x, sy = o.first.y, sz = o.first.z;        // (lanes >= n hold zeros)
+    for (int j0 = 64; j0 < o.n; j0 += 64) {
+        const PtsBatch t = pfn_load_batch(p, o.row0, o.n, j0, lane);
+        sx += t.x; sy += t.y; sz += t.z;
     }
     sx = wave_sum_f(sx); sy = wave_sum_f(sy); sz = wave_sum_f(sz);
     const float fn = (float)o.n;
@@ -1214,12 +1233,35 @@ __device__ __forceinline__ bool pillar_info(const PfnT& p, int gp, int lane, Pil
     const int xi = cell % p.nx, yi = (cell / p.nx) % p.ny;
     o.cx = __fadd_rn(__fmul_rn((float)xi, p.vx), p.x_off);      // model/pointpillars.py:156-171
     o.cy = __fadd_rn(__fmul_rn((float)yi, p.vy), p.y_off);
-    return true;
 }
-
-// Y[row][c] = features(row) . W[:, c]; part[blk][0/1][c] = sums of y, y^2 over this workgroup's rows
+// y[q] = features . W[:, lane * CPL + q] (rows >= FA of w are zero)
 template <int CPL>
-__global__ __launch_bounds__(256) void k_tr_pfn_lin(PfnT p, float* __restrict__ Y, float* __restrict__ part) {
+__device__ __forceinline__ void pfn_dense(const float (&f)[10], const float (&w)[10][CPL], float (&y)[CPL]) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) v = fmaf(f[k], w[k][q], v);
+        y[q] = v;
+    }
+}
+// for (every point j of the pillar) { f = its features (wave-uniform); BODY }
+#define PFN_FOR_POINTS(P, H, LANE, BODY)                                                                 \
+    for (int j0_ = 0; j0_ < (H).n; j0_ += 64) {                                                          \
+        const PtsBatch bt_ = (j0_ == 0) ? (H).first : pfn_load_batch((P), (H).row0, (H).n, j0_, (LANE)); \
+        const int cnt_ = min(64, (H).n - j0_);                                                           \
+        for (int jj_ = 0; jj_ < cnt_; ++jj_) {                                                           \
+            const int j = j0_ + jj_;                                                                     \
+            float f[10];                                                                                 \
+            pfn_features((P), pfn_bcast(bt_.x, jj_), pfn_bcast(bt_.y, jj_), pfn_bcast(bt_.z, jj_),       \
+                         pfn_bcast(bt_.it, jj_), (H).mx, (H).my, (H).mz, (H).cx, (H).cy, f);             \
+            BODY                                                                                         \
+        }                                                                                                \
+    }
+
+// part[blk][0/1][c] = sums of y, y^2 over this workgroup's rows
+template <int CPL>
+__global__ __launch_bounds__(256) void k_tr_pfn_lin(PfnT p, float* __restrict__ part) {
     __shared__ float sp[4][2][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
@@ -1234,20 +1276,15 @@ __global__ __launch_bounds__(256) void k_tr_pfn_lin(PfnT p, float* __restrict__ 
     const int total = p.pprefix[p.batch];
     int bcur = 0;
     for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
-        PillarInfo pi;
-        if (!pillar_info(p, gp, lane, pi, bcur)) continue;
-        for (int j = 0; j < pi.n; ++j) {
-            float f[10];
-            pfn_row_features<CPL>(p, p.pts_sorted + (size_t)(pi.row0 + j) * p.F, pi.mx, pi.my, pi.mz, pi.cx, pi.cy, f);
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                float y = 0.f;
-#pragma unroll
-                for (int k = 0; k < 10; ++k) y = fmaf(f[k], w[k][q], y);   // rows >= FA of w are zero
-                if (lane * CPL + q < C) Y[(size_t)(pi.row0 + j) * C + lane * CPL + q] = y;
-                s1[q] += y; s2[q] = fmaf(y, y, s2[q]);
-            }
-        }
+        PillarHead h;
+        pillar_head(p, gp, lane, bcur, h);
+        PFN_FOR_POINTS(p, h, lane, {
+            (void)j;
+            float y[CPL];
+            pfn_dense<CPL>(f, w, y);
+_Pragma("unroll")
+            for (int q = 0; q < CPL; ++q) { s1[q] += y[q]; s2[q] = fmaf(y[q], y[q], s2[q]); }
+        })
     }
 #pragma unroll
     for (int q = 0; q < CPL; ++q) { sp[wave][0][lane * CPL + q] = s1[q]; sp[wave][1][lane * CPL + q] = s2[q]; }
@@ -1261,11 +1298,16 @@ __global__ __launch_bounds__(256) void k_tr_pfn_lin(PfnT p, float* __restrict__ 
 // feat[pillar][c] = max over the T rows of relu(bn(y)) (padded rows: bn(0)); arg[pillar][c] = winning row, -1 = a padded
 // row, -2 = the max is not positive (no gradient)
 template <int CPL>
-__global__ __launch_bounds__(256) void k_tr_pfn_max(PfnT p, const float* __restrict__ Y, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void k_tr_pfn_max(PfnT p, const float* __restrict__ stats,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float* __restrict__ feat, int* __restrict__ arg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
+    float w[10][CPL];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) w[k][q] = (k < p.FA && lane * CPL + q < C) ? p.W[k * C + lane * CPL + q] : 0.f;
     float sc[CPL], sh[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
@@ -1277,27 +1319,29 @@ __global__ __launch_bounds__(256) void k_tr_pfn_max(PfnT p, const float* __restr
     const int total = p.pprefix[p.batch];
     int bcur = 0;
     for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
-        int b, pid;
-        pillar_of(p, gp, bcur, b, pid);
-        const int* ps = p.pillar_start + (size_t)b * (p.max_voxels + 1);
-        const int start = ps[pid];
-        const int n = min(ps[pid + 1] - start, p.T);
-        const long row0 = (long)p.offsets[b] + start;
+        PillarHead h;
+        pillar_head(p, gp, lane, bcur, h);
+        float best[CPL];
+        int bi[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { best[q] = -3.0e38f; bi[q] = -2; }
+        PFN_FOR_POINTS(p, h, lane, {
+            float y[CPL];
+            pfn_dense<CPL>(f, w, y);
+_Pragma("unroll")
+            for (int q = 0; q < CPL; ++q) {
+                const float v = fmaf(y[q], sc[q], sh[q]);
+                if (v > best[q]) { best[q] = v; bi[q] = j; }
+            }
+        })
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = lane * CPL + q;
             if (c >= C) continue;
-            float best = -3.0e38f;
-            int bi = -2;
-#pragma unroll 8
-            for (int j = 0; j < n; ++j) {
-                const float v = fmaf(Y[(size_t)(row0 + j) * C + c], sc[q], sh[q]);
-                if (v > best) { best = v; bi = j; }
-            }
-            if (n < p.T && sh[q] > best) { best = sh[q]; bi = -1; }   // a zero-padded row: Dense(0) = 0 -> BN
-            if (!(best > 0.f)) { best = 0.f; bi = -2; }
-            feat[((size_t)b * p.max_voxels + pid) * C + c] = best;     // rows of feat / arg: frame * max_voxels + pillar
-            arg[((size_t)b * p.max_voxels + pid) * C + c] = bi;
+            if (h.n < p.T && sh[q] > best[q]) { best[q] = sh[q]; bi[q] = -1; }   // a zero-padded row: Dense(0) = 0 -> BN
+            if (!(best[q] > 0.f)) { best[q] = 0.f; bi[q] = -2; }
+            feat[((size_t)h.b * p.max_voxels + h.pid) * C + c] = best[q];        // rows of feat / arg: frame * max_voxels + pillar
+            arg[((size_t)h.b * p.max_voxels + h.pid) * C + c] = bi[q];
         }
     }
 }
@@ -1323,13 +1367,19 @@ __global__ __launch_bounds__(256) void k_tr_scatter(const int* __restrict__ cell
 }
 
 // PFN backward, pass 1: the gradient of a pillar feature goes to its winning row; sums of g and g * yhat
+// (y of the winning row recomputed from that row's point: a per-lane gather out of the lines the wave has just read)
 template <int CPL>
-__global__ __launch_bounds__(256) void k_tr_pfn_bwd_reduce(PfnT p, const float* __restrict__ Y, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void k_tr_pfn_bwd_reduce(PfnT p, const float* __restrict__ stats,
                                                            const int* __restrict__ arg, const float* __restrict__ dcanvas,
                                                            float* __restrict__ part) {
     __shared__ float sp[4][2][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
+    float w[10][CPL];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) w[k][q] = (k < p.FA && lane * CPL + q < C) ? p.W[k * C + lane * CPL + q] : 0.f;
     float s1[CPL], s2[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) s1[q] = s2[q] = 0.f;
@@ -1337,18 +1387,24 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_reduce(PfnT p, const float* 
     int bcur = 0;
     const int ncanvas = p.nx * p.ny;
     for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
-        int b, pid;
-        pillar_of(p, gp, bcur, b, pid);
-        const int cell = p.pillar_cell[(size_t)b * p.max_voxels + pid] % ncanvas;    // (y, x): the z index drops out
-        const long row0 = (long)p.offsets[b] + p.pillar_start[(size_t)b * (p.max_voxels + 1) + pid];
+        PillarHead h;
+        pillar_head(p, gp, lane, bcur, h);
+        const int cell = p.pillar_cell[(size_t)h.b * p.max_voxels + h.pid] % ncanvas;    // (y, x): the z index drops out
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = lane * CPL + q;
             if (c >= C) continue;
-            const int a = arg[((size_t)b * p.max_voxels + pid) * C + c];
+            const int a = arg[((size_t)h.b * p.max_voxels + h.pid) * C + c];
             if (a == -2) continue;
-            const float g = dcanvas[((size_t)b * ncanvas + cell) * C + c];
-            const float y = (a >= 0) ? Y[(size_t)(row0 + a) * C + c] : 0.f;
+            const float g = dcanvas[((size_t)h.b * ncanvas + cell) * C + c];
+            float y = 0.f;
+            if (a >= 0) {
+                const float* pt = p.pts_sorted + (size_t)(h.row0 + a) * p.F;
+                float f[10];
+                pfn_features(p, pt[0], pt[1], pt[2], (p.F > 3) ? pt[3] : 0.f, h.mx, h.my, h.mz, h.cx, h.cy, f);
+#pragma unroll
+                for (int k = 0; k < 10; ++k) y = fmaf(f[k], w[k][q], y);
+            }
             const float yh = (y - stats[2 * c]) * stats[2 * c + 1];
             s1[q] += g; s2[q] = fmaf(g, yh, s2[q]);
         }
@@ -1364,18 +1420,21 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_reduce(PfnT p, const float* 
 
 // pass 2: dy of every real row (the mean terms of the BatchNorm gradient reach all of them), dW[f][c] partials
 template <int CPL>
-__global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* __restrict__ Y, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* __restrict__ stats,
                                                           const float* __restrict__ gamma, const int* __restrict__ arg,
                                                           const float* __restrict__ dcanvas, const float* __restrict__ sums,
                                                           const float* __restrict__ n_rows_dev, float* __restrict__ part) {
     __shared__ float sp[4][10][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
-    float dw[10][CPL];
+    float w[10][CPL], dw[10][CPL];
 #pragma unroll
     for (int k = 0; k < 10; ++k)
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) dw[k][q] = 0.f;
+        for (int q = 0; q < CPL; ++q) {
+            w[k][q] = (k < p.FA && lane * CPL + q < C) ? p.W[k * C + lane * CPL + q] : 0.f;
+            dw[k][q] = 0.f;
+        }
     const float n_rows = fmaxf(*n_rows_dev, 1.f);
     float mean[CPL], inv[CPL], gi[CPL], m1[CPL], m2[CPL];
 #pragma unroll
@@ -1392,30 +1451,28 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* _
     int bcur = 0;
     const int ncanvas = p.nx * p.ny;
     for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
-        PillarInfo pi;
-        if (!pillar_info(p, gp, lane, pi, bcur)) continue;
-        const int cell = p.pillar_cell[(size_t)pi.b * p.max_voxels + pi.pid] % ncanvas;
+        PillarHead h;
+        pillar_head(p, gp, lane, bcur, h);
+        const int cell = p.pillar_cell[(size_t)h.b * p.max_voxels + h.pid] % ncanvas;
         float g[CPL];
         int a[CPL];
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = lane * CPL + q;
-            a[q] = (c < C) ? arg[((size_t)pi.b * p.max_voxels + pi.pid) * C + c] : -2;
-            g[q] = (c < C && a[q] >= 0) ? dcanvas[((size_t)pi.b * ncanvas + cell) * C + c] : 0.f;
+            a[q] = (c < C) ? arg[((size_t)h.b * p.max_voxels + h.pid) * C + c] : -2;
+            g[q] = (c < C && a[q] >= 0) ? dcanvas[((size_t)h.b * ncanvas + cell) * C + c] : 0.f;
         }
-        for (int j = 0; j < pi.n; ++j) {       // (unrolled by four: 280 -> 405 us at B=32, the registers cost more than the loads in flight gain)
-            float f[10];
-            pfn_row_features<CPL>(p, p.pts_sorted + (size_t)(pi.row0 + j) * p.F, pi.mx, pi.my, pi.mz, pi.cx, pi.cy, f);
-#pragma unroll
+        PFN_FOR_POINTS(p, h, lane, {
+            float y[CPL];
+            pfn_dense<CPL>(f, w, y);
+_Pragma("unroll")
             for (int q = 0; q < CPL; ++q) {
-                const int c = lane * CPL + q;
-                if (c >= C) continue;
-                const float yh = (Y[(size_t)(pi.row0 + j) * C + c] - mean[q]) * inv[q];
+                const float yh = (y[q] - mean[q]) * inv[q];
                 const float dy = gi[q] * (((a[q] == j) ? g[q] : 0.f) - m1[q] - yh * m2[q]);
-#pragma unroll
+_Pragma("unroll")
                 for (int k = 0; k < 10; ++k) dw[k][q] = fmaf(f[k], dy, dw[k][q]);
             }
-        }
+        })
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k)
@@ -1598,25 +1655,30 @@ __global__ void k_tr_pfn_rows(const int* __restrict__ npillars, int batch, int T
     }
 }
 
+// Persistent PFN grids: one resident round of workgroups (a quarter-filled second round costs a whole one).  Resident
+// 4-wave workgroups per CU follow the kernels' register budgets: CPL 1 / 2 / 4 -> lin 8 / 7 / 4, max 7 / 5 / 4,
+// bwd_reduce 8 / 6 / 4, bwd_apply 6 / 4 / 3.
+static int pfn_blocks(int per_cu) { return std::min(TR_NPART, per_cu * 256); }
+
 template <int CPL>
 void pfn_forward(const TrainCtx& cx, const PfnT& p, const Lookup& L) {
     PP_LAUNCH("k_tr_pfn_rows", k_tr_pfn_rows, dim3(1), dim3(64), 0, cx.stream, p.npillars, p.batch, p.T, cx.pfn_nrows,
               cx.pfn_prefix);
-    PP_LAUNCH("k_tr_pfn_lin", (k_tr_pfn_lin<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, cx.pfn_y, cx.part);
-    bn_finalize(cx, cx.part, TR_NPART, p.C, 0.f, cx.pfn_nrows, 0.01f, 0, cx.pfn_stats, L.s("pfn/bn/moving_mean"),
+    const int nlin = pfn_blocks(CPL == 4 ? 4 : 7), nmax = pfn_blocks(CPL == 4 ? 4 : 5);
+    PP_LAUNCH("k_tr_pfn_lin", (k_tr_pfn_lin<CPL>), dim3(nlin), dim3(256), 0, cx.stream, p, cx.part);
+    bn_finalize(cx, cx.part, nlin, p.C, 0.f, cx.pfn_nrows, 0.01f, 0, cx.pfn_stats, L.s("pfn/bn/moving_mean"),
                 L.s("pfn/bn/moving_variance"), 1);
-    PP_LAUNCH("k_tr_pfn_max", (k_tr_pfn_max<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p, (const float*)cx.pfn_y,
+    PP_LAUNCH("k_tr_pfn_max", (k_tr_pfn_max<CPL>), dim3(nmax), dim3(256), 0, cx.stream, p,
               (const float*)cx.pfn_stats, L.p("pfn/bn/gamma"), L.p("pfn/bn/beta"), cx.pfn_feat, cx.pfn_arg);
 }
 
 template <int CPL>
 void pfn_backward(const TrainCtx& cx, const PfnT& p, const Lookup& L, const float* dcanvas) {
-    PP_LAUNCH("k_tr_pfn_bwd_reduce", (k_tr_pfn_bwd_reduce<CPL>), dim3(TR_NPART), dim3(256), 0, cx.stream, p,
-              (const float*)cx.pfn_y, (const float*)cx.pfn_stats, (const int*)cx.pfn_arg, dcanvas, cx.part);
-    col_reduce(cx, p.C, cx.pfn_sums, L.g("pfn/bn/beta"), L.g("pfn/bn/gamma"));
-    // (104 - 145 VGPRs: four resident workgroups per CU at most -- one round of workgroups, no quarter-filled second one)
-    const int nblk = std::min(TR_NPART, CPL == 4 ? 768 : 1024);
-    PP_LAUNCH("k_tr_pfn_bwd_apply", (k_tr_pfn_bwd_apply<CPL>), dim3(nblk), dim3(256), 0, cx.stream, p, (const float*)cx.pfn_y,
+    const int nred = pfn_blocks(CPL == 4 ? 4 : 6), nblk = pfn_blocks(CPL == 4 ? 3 : 4);
+    PP_LAUNCH("k_tr_pfn_bwd_reduce", (k_tr_pfn_bwd_reduce<CPL>), dim3(nred), dim3(256), 0, cx.stream, p,
+              (const float*)cx.pfn_stats, (const int*)cx.pfn_arg, dcanvas, cx.part);
+    col_reduce(cx, p.C, cx.pfn_sums, L.g("pfn/bn/beta"), L.g("pfn/bn/gamma"), cx.part, (long)2 * p.C, nred);
+    PP_LAUNCH("k_tr_pfn_bwd_apply", (k_tr_pfn_bwd_apply<CPL>), dim3(nblk), dim3(256), 0, cx.stream, p,
               (const float*)cx.pfn_stats, L.p("pfn/bn/gamma"), (const int*)cx.pfn_arg, dcanvas, (const float*)cx.pfn_sums,
               (const float*)cx.pfn_nrows, cx.part);
     const long n = (long)p.FA * p.C;
