@@ -1673,6 +1673,7 @@ int train_buffers(pp_engine* e) {
     A1(dalloc(e, &cx.pfn_sums, (size_t)2 * s.C));
     A1(dalloc(e, &cx.pfn_nrows, (size_t)1));
     A1(dalloc(e, &cx.pfn_prefix, B + 1));
+    A1(dalloc(e, &cx.pfn_rec, B * s.max_voxels * 2));
     A1(dalloc(e, &cx.canvas, B * s.ny * s.nx * s.C));
     A1(dalloc(e, &cx.dcanvas, B * s.ny * s.nx * s.C));
     size_t max_z = 1, max_d = 1;

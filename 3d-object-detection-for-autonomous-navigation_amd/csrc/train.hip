@@ -1166,6 +1166,7 @@ struct PfnT {
     const float* W;            // [FA][C]
     const int* pprefix;        // [batch + 1] exclusive prefix of npillars (k_tr_pfn_rows): the kernels walk the batch's
                                // REAL pillars, not the batch * max_voxels slots (12 000 per frame, a quarter of them used)
+    float4* rec;               // [pillars of the batch][2] pillar records (k_tr_pfn_lin writes them, the other kernels read)
 };
 // global pillar number gp -> (frame, pillar of the frame); bcur: the wave's frame cursor (gp only grows)
 __device__ __forceinline__ void pillar_of(const PfnT& p, int gp, int& bcur, int& b, int& pid) {
@@ -1234,6 +1235,31 @@ __device__ __forceinline__ void pillar_head(const PfnT& p, int gp, int lane, int
     o.cx = __fadd_rn(__fmul_rn((float)xi, p.vx), p.x_off);      // model/pointpillars.py:156-171
     o.cy = __fadd_rn(__fmul_rn((float)yi, p.vy), p.y_off);
 }
+// The pillar record k_tr_pfn_lin leaves for the three kernels behind it: (row0, n, frame * max_voxels + pillar, cell),
+// (mean x, y, z, -).  One 32-byte wave-uniform load instead of the frame search, four dependent index loads, a second
+// pass over the points and three wave reductions per pillar and kernel.
+__device__ __forceinline__ void pillar_record_store(const PfnT& p, int gp, const PillarHead& h, int lane) {
+    if (lane != 0) return;
+    const int cell = p.pillar_cell[(size_t)h.b * p.max_voxels + h.pid];
+    p.rec[2 * (size_t)gp] = make_float4(__int_as_float((int)h.row0), __int_as_float(h.n),
+                                        __int_as_float(h.b * p.max_voxels + h.pid), __int_as_float(cell));
+    p.rec[2 * (size_t)gp + 1] = make_float4(h.mx, h.my, h.mz, 0.f);
+}
+struct PillarRec { int n, slot, cellxy; long row0; float mx, my, mz, cx, cy; PtsBatch first; };
+__device__ __forceinline__ void pillar_record_load(const PfnT& p, int gp, int lane, PillarRec& o) {
+    const float4 r0 = p.rec[2 * (size_t)gp], r1 = p.rec[2 * (size_t)gp + 1];
+    o.row0 = (long)__builtin_amdgcn_readfirstlane(__float_as_int(r0.x));
+    o.n = __builtin_amdgcn_readfirstlane(__float_as_int(r0.y));
+    o.slot = __builtin_amdgcn_readfirstlane(__float_as_int(r0.z));
+    const int cell = __builtin_amdgcn_readfirstlane(__float_as_int(r0.w));
+    o.first = pfn_load_batch(p, o.row0, o.n, 0, lane);
+    o.mx = r1.x; o.my = r1.y; o.mz = r1.z;
+    const int ncanvas = p.nx * p.ny;
+    o.cellxy = cell % ncanvas;                                  // (y, x): the z index drops out
+    const int xi = cell % p.nx, yi = (cell / p.nx) % p.ny;
+    o.cx = __fadd_rn(__fmul_rn((float)xi, p.vx), p.x_off);      // model/pointpillars.py:156-171
+    o.cy = __fadd_rn(__fmul_rn((float)yi, p.vy), p.y_off);
+}
 // y[q] = features . W[:, lane * CPL + q] (rows >= FA of w are zero)
 template <int CPL>
 __device__ __forceinline__ void pfn_dense(const float (&f)[10], const float (&w)[10][CPL], float (&y)[CPL]) {
@@ -1278,6 +1304,7 @@ __global__ __launch_bounds__(256) void k_tr_pfn_lin(PfnT p, float* __restrict__ 
     for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
         PillarHead h;
         pillar_head(p, gp, lane, bcur, h);
+        pillar_record_store(p, gp, h, lane);
         PFN_FOR_POINTS(p, h, lane, {
             (void)j;
             float y[CPL];
@@ -1317,10 +1344,9 @@ __global__ __launch_bounds__(256) void k_tr_pfn_max(PfnT p, const float* __restr
         sh[q] = (c < C) ? beta[c] - stats[2 * c] * inv : 0.f;
     }
     const int total = p.pprefix[p.batch];
-    int bcur = 0;
     for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
-        PillarHead h;
-        pillar_head(p, gp, lane, bcur, h);
+        PillarRec h;
+        pillar_record_load(p, gp, lane, h);
         float best[CPL];
         int bi[CPL];
 #pragma unroll
@@ -1340,8 +1366,8 @@ _Pragma("unroll")
             if (c >= C) continue;
             if (h.n < p.T && sh[q] > best[q]) { best[q] = sh[q]; bi[q] = -1; }   // a zero-padded row: Dense(0) = 0 -> BN
             if (!(best[q] > 0.f)) { best[q] = 0.f; bi[q] = -2; }
-            feat[((size_t)h.b * p.max_voxels + h.pid) * C + c] = best[q];        // rows of feat / arg: frame * max_voxels + pillar
-            arg[((size_t)h.b * p.max_voxels + h.pid) * C + c] = bi[q];
+            feat[(size_t)h.slot * C + c] = best[q];                              // rows of feat / arg: frame * max_voxels + pillar
+            arg[(size_t)h.slot * C + c] = bi[q];
         }
     }
 }
@@ -1384,19 +1410,18 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_reduce(PfnT p, const float* 
 #pragma unroll
     for (int q = 0; q < CPL; ++q) s1[q] = s2[q] = 0.f;
     const int total = p.pprefix[p.batch];
-    int bcur = 0;
     const int ncanvas = p.nx * p.ny;
     for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
-        PillarHead h;
-        pillar_head(p, gp, lane, bcur, h);
-        const int cell = p.pillar_cell[(size_t)h.b * p.max_voxels + h.pid] % ncanvas;    // (y, x): the z index drops out
+        PillarRec h;
+        pillar_record_load(p, gp, lane, h);
+        const size_t crow = (size_t)(h.slot / p.max_voxels) * ncanvas + h.cellxy;        // canvas row of the pillar
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = lane * CPL + q;
             if (c >= C) continue;
-            const int a = arg[((size_t)h.b * p.max_voxels + h.pid) * C + c];
+            const int a = arg[(size_t)h.slot * C + c];
             if (a == -2) continue;
-            const float g = dcanvas[((size_t)h.b * ncanvas + cell) * C + c];
+            const float g = dcanvas[crow * C + c];
             float y = 0.f;
             if (a >= 0) {
                 const float* pt = p.pts_sorted + (size_t)(h.row0 + a) * p.F;
@@ -1448,19 +1473,18 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* _
         m2[q] = ok ? sums[C + c] / n_rows : 0.f;
     }
     const int total = p.pprefix[p.batch];
-    int bcur = 0;
     const int ncanvas = p.nx * p.ny;
     for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
-        PillarHead h;
-        pillar_head(p, gp, lane, bcur, h);
-        const int cell = p.pillar_cell[(size_t)h.b * p.max_voxels + h.pid] % ncanvas;
+        PillarRec h;
+        pillar_record_load(p, gp, lane, h);
+        const size_t crow = (size_t)(h.slot / p.max_voxels) * ncanvas + h.cellxy;
         float g[CPL];
         int a[CPL];
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = lane * CPL + q;
-            a[q] = (c < C) ? arg[((size_t)h.b * p.max_voxels + h.pid) * C + c] : -2;
-            g[q] = (c < C && a[q] >= 0) ? dcanvas[((size_t)h.b * ncanvas + cell) * C + c] : 0.f;
+            a[q] = (c < C) ? arg[(size_t)h.slot * C + c] : -2;
+            g[q] = (c < C && a[q] >= 0) ? dcanvas[crow * C + c] : 0.f;
         }
         PFN_FOR_POINTS(p, h, lane, {
             float y[CPL];
@@ -1721,7 +1745,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
     p.with_distance = s.with_dist;
     p.vx = s.vx; p.vy = s.vy; p.x_off = s.x_off; p.y_off = s.y_off;
     p.pts_sorted = cx.pts_sorted; p.offsets = cx.offsets; p.pillar_start = cx.pillar_start; p.pillar_cell = cx.pillar_cell;
-    p.npillars = cx.npillars; p.W = L.p("pfn/dense/kernel"); p.pprefix = cx.pfn_prefix;
+    p.npillars = cx.npillars; p.W = L.p("pfn/dense/kernel"); p.pprefix = cx.pfn_prefix; p.rec = cx.pfn_rec;
     const int cpl = (s.C + 63) / 64;
     const RowMap ident{1, 0, 0};
     const size_t HW = (size_t)s.head_h * s.head_w;
