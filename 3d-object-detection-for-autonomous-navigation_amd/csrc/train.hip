@@ -171,6 +171,16 @@ struct T2Stage {
     static constexpr int LDR = T2_LDR(KCH);
     static_assert(KC || EPT == 8 || EPT == 16, "transposed staging: 2 or 4 k per thread");
     float v[EPT];
+    // Transposed form, thread -> (group of 4 rows, group of KPT k): lane bits [1:0] walk the rows (four lanes = 64
+    // contiguous bytes of one k line of the operand), the next bits the k groups, the rest (the waves) the remaining row
+    // groups.  The LDS image is [row][k] with 80- / 144-byte rows, so the bank of a lane's 4-byte store is
+    // 16 * (row group & 1) + k group + const (mod 32): with the row groups in the LOW lane bits and 16 of them per wave
+    // (the first version: row group = tid % 16) a 32-lane store group hit two banks per k group -- 8-way conflicts on
+    // every one of the 12 stores a thread issues per operand and chunk (SQ_LDS_BANK_CONFLICT 78 % of the LDS-active
+    // cycles of the weight-gradient products, 66 % of the forward ones); with 8 k groups x 2 row-group parities per
+    // store group it is 2-way, which a ds_write_b32 absorbs.
+    static __device__ __forceinline__ int kgi(int tid) { return (tid >> 2) % (KCH * 4 / EPT); }
+    static __device__ __forceinline__ int rgi(int tid) { return (tid & 3) + 4 * (tid / (KCH * 16 / EPT)); }
     // p(r, k) = base[r * sr + k * sk]; rows >= nrows and k >= kend read as zero
     __device__ __forceinline__ void load(const float* __restrict__ base, long sr, long sk, int row0, int nrows, int k0, int kend, int tid) {
         if (KC) {
@@ -184,8 +194,8 @@ struct T2Stage {
                 v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
             }
         } else {
-            constexpr int KPT = EPT / 4, RG = ROWS / 4;    // k per thread; groups of 4 rows
-            const int r = row0 + (tid % RG) * 4, k = k0 + (tid / RG) * KPT;
+            constexpr int KPT = EPT / 4;                   // k per thread (KCH / KPT k groups x ROWS / 4 row groups = 256 threads)
+            const int r = row0 + rgi(tid) * 4, k = k0 + kgi(tid) * KPT;
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -210,8 +220,8 @@ struct T2Stage {
                 *reinterpret_cast<uint4*>(d + 2 * PL + j) = make_uint4(l[0], l[1], l[2], l[3]);
             }
         } else {
-            constexpr int KPT = EPT / 4, RG = ROWS / 4;
-            __bf16* d = lds + ((tid % RG) * 4) * LDR + (tid / RG) * KPT;
+            constexpr int KPT = EPT / 4;
+            __bf16* d = lds + (rgi(tid) * 4) * LDR + kgi(tid) * KPT;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                  // row r + i: KPT consecutive k
                 unsigned h[KPT / 2], m[KPT / 2], l[KPT / 2];
