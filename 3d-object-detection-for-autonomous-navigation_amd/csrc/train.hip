@@ -1211,16 +1211,37 @@ __device__ __forceinline__ PtsBatch pfn_load_batch(const PfnT& p, long row0, int
 __device__ __forceinline__ float pfn_bcast(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
-// the decorated features of a pillar row from wave-uniform coordinates: raw F | xyz - mean | xy - centre | [norm]
-// (f[0..9], unused tail zero; written with selects so that f stays in registers)
+// The decorated features of a pillar row from wave-uniform coordinates, in a CANONICAL order that does not depend on
+// the configuration: x y z | intensity | xyz - mean | xy - centre | norm.  The configuration lives in the weights: a
+// kernel loads row canon_row(c) of the Dense kernel for canonical feature c (none -- zeros -- for the intensity of a
+// 3-feature cloud or the norm without with_distance), so the ten-FMA chain visits the real rows in their own order
+// with exact no-ops in between: bit-identical to the row-order chain, and no per-point selects.  (The first version
+// ordered the features by the configuration with selects and evaluated the norm's sqrt before selecting it away:
+// ~95 wave-instructions per point in k_tr_pfn_lin, VALU-bound.)
+__device__ __forceinline__ int pfn_canon_row(const PfnT& p, int c) {     // Dense-kernel row of canonical feature c, or -1
+    const bool f4 = p.F > 3;
+    if (c < 3) return c;
+    if (c == 3) return f4 ? 3 : -1;
+    const int r = (f4 ? 4 : 3) + (c - 4);                  // c = 4..8: the five offsets; c = 9: the norm
+    if (c == 9 && !p.with_distance) return -1;
+    return (r < p.FA) ? r : -1;
+}
 __device__ __forceinline__ void pfn_features(const PfnT& p, float x, float y, float z, float it, float mx, float my, float mz,
                                              float cx, float cy, float (&f)[10]) {
-    const bool f4 = p.F > 3;
-    const float e0 = x - mx, e1 = y - my, e2 = z - mz, e3 = x - cx, e4 = y - cy;
-    const float e5 = p.with_distance ? sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z))) : 0.f;
-    f[0] = x; f[1] = y; f[2] = z;
-    f[3] = f4 ? it : e0; f[4] = f4 ? e0 : e1; f[5] = f4 ? e1 : e2; f[6] = f4 ? e2 : e3; f[7] = f4 ? e3 : e4;
-    f[8] = f4 ? e4 : e5; f[9] = f4 ? e5 : 0.f;
+    f[0] = x; f[1] = y; f[2] = z; f[3] = it;
+    f[4] = x - mx; f[5] = y - my; f[6] = z - mz; f[7] = x - cx; f[8] = y - cy;
+    f[9] = 0.f;
+    if (p.with_distance) f[9] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));   // (uniform branch)
+}
+// w[c][q] = Dense kernel row of canonical feature c, this lane's channels
+template <int CPL>
+__device__ __forceinline__ void pfn_load_weights(const PfnT& p, int lane, float (&w)[10][CPL]) {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+        const int r = pfn_canon_row(p, c);
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) w[c][q] = (r >= 0 && lane * CPL + q < p.C) ? p.W[r * p.C + lane * CPL + q] : 0.f;
+    }
 }
 // pillar geometry with the first 64 points already in the lanes: frame, row range, mean (lane-strided partial sums,
 // then the xor tree), centre
@@ -1302,10 +1323,7 @@ __global__ __launch_bounds__(256) void k_tr_pfn_lin(PfnT p, float* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
     float w[10][CPL];
-#pragma unroll
-    for (int k = 0; k < 10; ++k)
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) w[k][q] = (k < p.FA && lane * CPL + q < C) ? p.W[k * C + lane * CPL + q] : 0.f;
+    pfn_load_weights<CPL>(p, lane, w);
     float s1[CPL], s2[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) s1[q] = s2[q] = 0.f;
@@ -1341,10 +1359,7 @@ __global__ __launch_bounds__(256) void k_tr_pfn_max(PfnT p, const float* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
     float w[10][CPL];
-#pragma unroll
-    for (int k = 0; k < 10; ++k)
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) w[k][q] = (k < p.FA && lane * CPL + q < C) ? p.W[k * C + lane * CPL + q] : 0.f;
+    pfn_load_weights<CPL>(p, lane, w);
     float sc[CPL], sh[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
@@ -1412,10 +1427,7 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_reduce(PfnT p, const float* 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
     float w[10][CPL];
-#pragma unroll
-    for (int k = 0; k < 10; ++k)
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) w[k][q] = (k < p.FA && lane * CPL + q < C) ? p.W[k * C + lane * CPL + q] : 0.f;
+    pfn_load_weights<CPL>(p, lane, w);
     float s1[CPL], s2[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) s1[q] = s2[q] = 0.f;
@@ -1462,14 +1474,12 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* _
     __shared__ float sp[4][10][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
-    float w[10][CPL], dw[10][CPL];
+    float w[10][CPL], dw[10][CPL];                          // (canonical feature order, as pfn_features)
+    pfn_load_weights<CPL>(p, lane, w);
 #pragma unroll
     for (int k = 0; k < 10; ++k)
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            w[k][q] = (k < p.FA && lane * CPL + q < C) ? p.W[k * C + lane * CPL + q] : 0.f;
-            dw[k][q] = 0.f;
-        }
+        for (int q = 0; q < CPL; ++q) dw[k][q] = 0.f;
     const float n_rows = fmaxf(*n_rows_dev, 1.f);
     float mean[CPL], inv[CPL], gi[CPL], m1[CPL], m2[CPL];
 #pragma unroll
@@ -1513,9 +1523,11 @@ _Pragma("unroll")
 #pragma unroll
         for (int q = 0; q < CPL; ++q) sp[wave][k][lane * CPL + q] = dw[k][q];
     __syncthreads();
-    for (int e = threadIdx.x; e < p.FA * C; e += 256) {
-        const int k = e / C, c = e - k * C;
-        part[(size_t)blockIdx.x * p.FA * C + e] = ((sp[0][k][c] + sp[1][k][c]) + sp[2][k][c]) + sp[3][k][c];
+    for (int cf = 0; cf < 10; ++cf) {                       // canonical feature -> its row of the Dense-kernel gradient
+        const int k = pfn_canon_row(p, cf);
+        if (k < 0) continue;
+        for (int c = threadIdx.x; c < C; c += 256)
+            part[(size_t)blockIdx.x * p.FA * C + (size_t)k * C + c] = ((sp[0][cf][c] + sp[1][cf][c]) + sp[2][cf][c]) + sp[3][cf][c];
     }
 }
 
