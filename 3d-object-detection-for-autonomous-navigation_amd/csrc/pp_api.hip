@@ -81,6 +81,8 @@ struct pp_engine {
     int* d_loss_npos = nullptr;
     double* d_loss_partials = nullptr;
     float* d_loss_out = nullptr;
+    float* h_train_losses = nullptr;      // page-locked [8]: the losses of a step launched by pp_train_step_async
+    bool train_pending = false;           // ... which pp_train_step_wait has not collected yet
     float* d_head_grad = nullptr;
     int* d_integ = nullptr;
     uint8_t* d_mask = nullptr;
@@ -829,6 +831,7 @@ int pp_destroy(pp_handle e) {
     for (PpFeed* f : e->h_feed) if (f) (void)hipHostFree(f);
     if (e->ev_up) (void)hipEventDestroy(e->ev_up);
     if (e->ev_tgt) (void)hipEventDestroy(e->ev_tgt);
+    if (e->h_train_losses) (void)hipHostFree(e->h_train_losses);
     for (hipEvent_t ev : e->ev_read) if (ev) (void)hipEventDestroy(ev);
     if (e->d_voxels) (void)hipFree(e->d_voxels);
     if (e->d_numpts) (void)hipFree(e->d_numpts);
@@ -1773,11 +1776,12 @@ int pp_train_layout_entry(pp_handle e, int32_t i, const char** name, int64_t* of
     return PP_OK;
 }
 
-int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float* state_dev, const int32_t* labels,
-                  const float* reg_targets, int32_t batch, const pp_loss_config* lc, float* losses) {
+int pp_train_step_async(pp_handle e, const float* params_dev, float* grads_dev, float* state_dev, const int32_t* labels,
+                        const float* reg_targets, int32_t batch, const pp_loss_config* lc) {
     if (!e) return PP_ERR_ARG;
-    if (!params_dev || !grads_dev || !state_dev || !labels || !reg_targets || !lc || !losses)
+    if (!params_dev || !grads_dev || !state_dev || !labels || !reg_targets || !lc)
         return fail(e, PP_ERR_ARG, "pp_train_step: null argument");
+    if (e->train_pending) return fail(e, PP_ERR_STATE, "pp_train_step_async: the step before has not been waited for");
     if (!e->anchors_ready) return fail(e, PP_ERR_STATE, "pp_train_step: anchors not set");
     if (e->cur_batch < 1 || e->cur_batch != batch)
         return fail(e, PP_ERR_STATE, "pp_train_step: %d frames are resident, batch is %d (upload the frames first)", e->cur_batch, batch);
@@ -1881,12 +1885,38 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
     }
     if (st) return fail(e, st, "pp_train_step: configuration not supported by the training kernels");
     HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipMemcpyAsync(losses, e->d_loss_out, 8 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (!e->h_train_losses && hipHostMalloc((void**)&e->h_train_losses, 8 * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e, PP_ERR_HIP, "pp_train_step: hipHostMalloc failed");
+    }
+    HIPCHK(e, hipMemcpyAsync(e->h_train_losses, e->d_loss_out, 8 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    // this input buffer (and its zero-copy descriptor) is free again once the step is through: the NEXT batch may be
+    // uploaded into the other one while this step runs (pp_upload_points_async between _async and _wait)
     HIPCHK(e, hipEventRecord(e->ev_read[e->in_buf], e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
     e->results_batch = 0;          // the head map now holds training-mode outputs, not detections
     e->cls_plane_live = false;
+    e->train_pending = true;
     return PP_OK;
+}
+
+int pp_train_step_wait(pp_handle e, float* losses) {
+    if (!e) return PP_ERR_ARG;
+    if (!losses) return fail(e, PP_ERR_ARG, "pp_train_step_wait: losses is NULL");
+    if (!e->train_pending) return fail(e, PP_ERR_STATE, "pp_train_step_wait: no step in flight");
+    (void)hipSetDevice(e->device);
+    e->train_pending = false;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    memcpy(losses, e->h_train_losses, 8 * sizeof(float));
+    return PP_OK;
+}
+
+int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float* state_dev, const int32_t* labels,
+                  const float* reg_targets, int32_t batch, const pp_loss_config* lc, float* losses) {
+    if (!e) return PP_ERR_ARG;
+    if (!losses) return fail(e, PP_ERR_ARG, "pp_train_step: null argument");
+    int st = pp_train_step_async(e, params_dev, grads_dev, state_dev, labels, reg_targets, batch, lc);
+    if (st) return st;
+    return pp_train_step_wait(e, losses);
 }
 
 int pp_train_graph_stats(pp_handle e, int32_t* captures, int32_t* replays) {

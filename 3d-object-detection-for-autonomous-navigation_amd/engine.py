@@ -444,22 +444,40 @@ class Engine:
         """A page-locked numpy array (PinnedArray) for targets / frames the loader fills in place."""
         return PinnedArray(self._lib, shape, dtype)
 
-    def train_step(self, params_ptr, grads_ptr, state_ptr, labels, reg_targets):
-        """Forward (training mode) + loss + backward on the resident frames (pp_train_step).  The three pointers
-        are integer device addresses of the flat float32 buffers; returns the reference's loss scalars."""
+    @staticmethod
+    def _loss_dict(losses):
+        return {"loss": float(losses[0]), "loc_loss_reduced": float(losses[1]), "cls_loss_reduced": float(losses[2]),
+                "dir_loss_reduced": float(losses[3]), "cls_pos_loss": float(losses[4]), "cls_neg_loss": float(losses[5]),
+                "num_positives": int(losses[6])}
+
+    def train_step_async(self, params_ptr, grads_ptr, state_ptr, labels, reg_targets):
+        """Enqueue forward (training mode) + loss + backward on the resident frames (pp_train_step_async) and return.
+        Until train_step_wait() the next batch may be uploaded (upload_async: the handle's other input buffer, on the
+        copy stream beside the running kernels); labels / reg_targets are held here until then."""
         labels = _i32(np.asarray(labels))
         batch = labels.shape[0]
         reg_targets = _f32(np.asarray(reg_targets).reshape(batch, self.d.num_anchors, 7))   # (no copy when already so)
         if labels.shape != (batch, self.d.num_anchors):
             raise ValueError(f"labels must be [B, {self.d.num_anchors}]")
-        losses = np.zeros(8, np.float32)
         lc = self.loss_config()
-        self._check(self._lib.pp_train_step(self._h, ctypes.c_void_p(int(params_ptr)), ctypes.c_void_p(int(grads_ptr)),
-                                            ctypes.c_void_p(int(state_ptr)), _ptr(labels), _ptr(reg_targets), batch,
-                                            ctypes.byref(lc), _ptr(losses)), "pp_train_step")
-        return {"loss": float(losses[0]), "loc_loss_reduced": float(losses[1]), "cls_loss_reduced": float(losses[2]),
-                "dir_loss_reduced": float(losses[3]), "cls_pos_loss": float(losses[4]), "cls_neg_loss": float(losses[5]),
-                "num_positives": int(losses[6])}
+        self._check(self._lib.pp_train_step_async(self._h, ctypes.c_void_p(int(params_ptr)),
+                                                  ctypes.c_void_p(int(grads_ptr)), ctypes.c_void_p(int(state_ptr)),
+                                                  _ptr(labels), _ptr(reg_targets), batch, ctypes.byref(lc)),
+                    "pp_train_step_async")
+        self._train_targets = (labels, reg_targets)      # the copy engine reads them while the forward pass runs
+
+    def train_step_wait(self):
+        """Wait for the step train_step_async() launched; returns the reference's loss scalars."""
+        losses = np.zeros(8, np.float32)
+        self._check(self._lib.pp_train_step_wait(self._h, _ptr(losses)), "pp_train_step_wait")
+        self._train_targets = None
+        return self._loss_dict(losses)
+
+    def train_step(self, params_ptr, grads_ptr, state_ptr, labels, reg_targets):
+        """Forward (training mode) + loss + backward on the resident frames (pp_train_step).  The three pointers
+        are integer device addresses of the flat float32 buffers; returns the reference's loss scalars."""
+        self.train_step_async(params_ptr, grads_ptr, state_ptr, labels, reg_targets)
+        return self.train_step_wait()
 
     def timer_start(self):
         self._check(self._lib.pp_timer_start(self._h), "pp_timer_start")

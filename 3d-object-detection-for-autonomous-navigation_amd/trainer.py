@@ -35,6 +35,7 @@ class Trainer:
         import torch
         self.torch = torch
         self.engine = Engine(config, max_batch=max_batch, max_points_per_frame=max_points_per_frame, device=device)
+        self._prefetched = None      # the TrainBatch whose points are already on their way (forward_backward(prefetch=))
         d = self.engine.d
         self.layout, n_params, n_state = self.engine.train_layout()
         self.device = torch.device("cuda", device)
@@ -112,13 +113,23 @@ class Trainer:
         st.reg_targets[...] = np.asarray(reg_targets, dtype=np.float32).reshape(B, d.num_anchors, 7)
         return st
 
-    def forward_backward(self, frames, labels=None, reg_targets=None):
-        """frames: a list of clouds with labels / reg_targets, or one TrainBatch from stage()."""
+    def forward_backward(self, frames, labels=None, reg_targets=None, prefetch=None):
+        """frames: a list of clouds with labels / reg_targets, or one TrainBatch from stage().
+        prefetch: the TrainBatch of the NEXT step -- its points go to the GPU (the handle's other input buffer, the copy
+        stream) while this step's kernels run, the loader's hand-over of train.py:228-304; pass that same batch as
+        `frames` of the next call."""
         if isinstance(frames, TrainBatch):
             tb = frames
-            self.engine.upload_async(tb.points)
-            return self.engine.train_step(self.params.data_ptr(), self.grads.data_ptr(), self.state.data_ptr(), tb.labels,
-                                          tb.reg_targets)
+            if self._prefetched is not tb:
+                self.engine.upload_async(tb.points)
+            self._prefetched = None
+            self.engine.train_step_async(self.params.data_ptr(), self.grads.data_ptr(), self.state.data_ptr(), tb.labels,
+                                         tb.reg_targets)
+            if isinstance(prefetch, TrainBatch):
+                self.engine.upload_async(prefetch.points)
+                self._prefetched = prefetch
+            return self.engine.train_step_wait()
+        self._prefetched = None
         self.engine.upload(frames)
         return self.engine.train_step(self.params.data_ptr(), self.grads.data_ptr(), self.state.data_ptr(), labels,
                                       reg_targets)
@@ -132,8 +143,8 @@ class Trainer:
         self.optimizer.apply_gradients(self.grads)
         self.torch.cuda.current_stream(self.device).synchronize()
 
-    def step(self, frames, labels=None, reg_targets=None, dist=None):
-        out = self.forward_backward(frames, labels, reg_targets)
+    def step(self, frames, labels=None, reg_targets=None, dist=None, prefetch=None):
+        out = self.forward_backward(frames, labels, reg_targets, prefetch=prefetch)
         self.apply_gradients(dist)
         return out
 

@@ -430,14 +430,15 @@ def train_leg(pp, local_rank, rank, n_gpus, dist, comm_dev, barrier, steps=20, b
         labels[b, pos] = 1
         reg[b, pos] = rng.normal(0, 0.4, (30, 7)).astype(np.float32)
     # two batches staged in page-locked memory take turns (the loader's hand-over, train.py:265-304: a different batch
-    # every step); the host-to-device copies of points, labels and regression targets are inside every timed step
+    # every step); the host-to-device copies of points, labels and regression targets are inside every timed step -- the
+    # targets travel behind the forward pass, the NEXT step's points (prefetch=) beside this step's kernels
     staged = [tr.stage(frames, labels, reg), tr.stage(frames[::-1], labels[::-1], reg[::-1])]
     for i in range(4):
-        out = tr.step(staged[i % 2], dist=dist)
+        out = tr.step(staged[i % 2], dist=dist, prefetch=staged[(i + 1) % 2])
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        out = tr.step(staged[i % 2], dist=dist)
+        out = tr.step(staged[i % 2], dist=dist, prefetch=staged[(i + 1) % 2])
     barrier()
     el = pp.frame_shard.max_over_ranks(time.perf_counter() - t0, dist, comm_dev)
     res = {"workload": f"cfg-A training step, {batch} frames/GPU x 16384 pts, {tr.params.numel()} trainable parameters "

@@ -303,6 +303,15 @@ int pp_train_layout_entry(pp_handle h, int32_t i, const char** name, int64_t* of
 int pp_train_step(pp_handle h, const float* params_dev, float* grads_dev, float* state_dev, const int32_t* labels,
                   const float* reg_targets, int32_t batch, const pp_loss_config* cfg, float* losses);
 
+/* The same step in two halves, for the loader's hand-over (the reference's tf.data pipeline prepares batch n + 1 while
+ * trainStep n runs, train.py:228-304): _async enqueues the step on the handle's stream and returns; between the two
+ * calls the caller may upload the NEXT batch (pp_upload_points_async: it goes into the handle's other input buffer on
+ * the copy stream, beside the running kernels); _wait returns when the step has finished, with its losses.  labels /
+ * reg_targets must stay unchanged until _wait returns.  pp_train_step = _async + _wait. */
+int pp_train_step_async(pp_handle h, const float* params_dev, float* grads_dev, float* state_dev, const int32_t* labels,
+                        const float* reg_targets, int32_t batch, const pp_loss_config* cfg);
+int pp_train_step_wait(pp_handle h, float* losses);
+
 /* How often pp_train_step captured a hipGraph and how often it replayed one (one graph per input buffer of the
  * handle): steady-state steps must replay -- a regression check, not part of the reference's surface. */
 int pp_train_graph_stats(pp_handle h, int32_t* captures, int32_t* replays);

@@ -185,7 +185,20 @@ def test_optimizer_steps_reduce_the_loss_and_export_to_inference(pp, hip_lib):
     st = tr.stage(frames, labels, reg)
     b = tr.forward_backward(st)
     assert a["loss"] == b["loss"] and np.array_equal(tr.grads.cpu().numpy(), ga)
+    # the loader's hand-over: the NEXT batch's points uploaded while this step runs (pp_train_step_async / _wait);
+    # the prefetched batch is then consumed without a second upload, and nothing changes in the numbers
+    st2 = tr.stage(frames[::-1], labels[::-1], reg[::-1])
+    c0 = tr.forward_backward(st2)
+    gc = tr.grads.cpu().numpy().copy()
+    b1 = tr.forward_backward(st, prefetch=st2)
+    assert b1["loss"] == b["loss"] and np.array_equal(tr.grads.cpu().numpy(), ga)
+    assert tr._prefetched is st2
+    c1 = tr.forward_backward(st2, prefetch=st)
+    assert c1["loss"] == c0["loss"] and np.array_equal(tr.grads.cpu().numpy(), gc)
+    b2 = tr.forward_backward(st)
+    assert b2["loss"] == b["loss"] and np.array_equal(tr.grads.cpu().numpy(), ga)
     st.close()
+    st2.close()
     # the trained tensors (and the updated moving statistics) load into an inference engine
     w = tr.weights()
     pp.weights.check_weights(d, w)
