@@ -373,19 +373,19 @@ __global__ __launch_bounds__(256, 2) void k_tr_gemm2(TGemm2 a2) {
 // depend on nothing else: at the reference's 2-frame batch each is a handful of workgroups living on memory latency,
 // and a launch of its own costs as much as the product).  64 x 64 tiles, 64-wide chunks; workgroups [0, n1) run
 // product 1 (TN: A and B with unit stride across k), the rest product 2 (A along k; B2KC: B along k).
-template <bool B2KC>
+template <bool B2KC, int KCH>
 __global__ __launch_bounds__(256, 2) void k_tr_gemm2_pair(TGemm2 p1, TGemm2 p2) {
-    __shared__ __attribute__((aligned(16))) __bf16 sA[3 * 64 * T2_LDR(64)];
-    __shared__ __attribute__((aligned(16))) __bf16 sB[3 * 64 * T2_LDR(64)];
+    __shared__ __attribute__((aligned(16))) __bf16 sA[3 * 64 * T2_LDR(KCH)];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[3 * 64 * T2_LDR(KCH)];
     const int n1 = p1.gx * p1.gy * p1.gz;
     int id = (int)blockIdx.x;
     if (id < n1) {
         const int bx = id % p1.gx; id /= p1.gx;
-        t2_gemm_tile<1, 1, false, false, 64>(p1, bx, id % p1.gy, id / p1.gy, sA, sB);
+        t2_gemm_tile<1, 1, false, false, KCH>(p1, bx, id % p1.gy, id / p1.gy, sA, sB);
     } else {
         id -= n1;
         const int bx = id % p2.gx; id /= p2.gx;
-        t2_gemm_tile<1, 1, true, B2KC, 64>(p2, bx, id % p2.gy, id / p2.gy, sA, sB);
+        t2_gemm_tile<1, 1, true, B2KC, KCH>(p2, bx, id % p2.gy, id / p2.gy, sA, sB);
     }
 }
 
@@ -674,13 +674,22 @@ static void tr_gemm(const TrainCtx& cx, const float* A, long sam, long sak, cons
 static void tr_gemm_pair(const TrainCtx& cx, const GemmCall& w, const GemmCall& d) {
     const bool forms = w.sak != 1 && w.sbk != 1 && d.sak == 1;
     if (forms && gemm2_eligible(w) && gemm2_eligible(d) && w.defer && w.stat_part == nullptr && d.stat_part == nullptr) {
-        auto plan = [](const GemmCall& c, int ks, int& kper, int& nks) {
-            kper = ((c.K + ks - 1) / ks + 63) / 64 * 64;
+        // 64-wide chunks while the launch lives on latency, the 32-wide ones (five workgroups per CU) beyond: two
+        // half-filled launches of a large batch -- block3's 640 + 640 workgroups at B=32 -- fill the chip together
+        static int pair_big = -1;      // PP_TRAIN_PAIR_BIG=0: pairs only in the latency regime (the round-3 first version)
+        if (pair_big < 0) { const char* e = getenv("PP_TRAIN_PAIR_BIG"); pair_big = (e && e[0] == '0') ? 0 : 1; }
+        int ks1, ks2, kper1, kper2, n1, n2;
+        TGemm g1 = gemm_args(cx, w, ks1);
+        int ksd;
+        (void)gemm_args(cx, d, ksd);
+        const auto tiles = [](const GemmCall& c) { return (long)((c.M + 63) / 64) * ((c.N + 63) / 64); };
+        const bool wide = tiles(w) * ks1 + tiles(d) * ksd < 2 * TR_LATENCY_WGS;
+        const int kround = wide ? 64 : 32;
+        auto plan = [kround](const GemmCall& c, int ks, int& kper, int& nks) {
+            kper = ((c.K + ks - 1) / ks + kround - 1) / kround * kround;
             nks = (c.K + kper - 1) / kper;
             return (long)((c.M + 63) / 64) * ((c.N + 63) / 64) * nks;
         };
-        int ks1, ks2, kper1, kper2, n1, n2;
-        TGemm g1 = gemm_args(cx, w, ks1);
         const long wg1 = plan(w, ks1, kper1, n1);
         // (the second product's partial tiles, if it is split, lie behind the first one's region)
         const long region1 = (n1 > 1) ? ((long)n1 * w.M * w.N + 63) / 64 * 64 : 0;
@@ -689,15 +698,16 @@ static void tr_gemm_pair(const TrainCtx& cx, const GemmCall& w, const GemmCall& 
         TGemm g2 = gemm_args(cx, d, ks2);
         g_arena_used = saved;
         const long wg2 = plan(d, ks2, kper2, n2);
-        if (wg1 + wg2 < 2 * TR_LATENCY_WGS) {
+        if (wide || pair_big) {
             g1.kper = kper1; g2.kper = kper2;
             TGemm2 p1{g1, nullptr, (w.N + 63) / 64, (w.M + 63) / 64, n1};
             TGemm2 p2{g2, nullptr, (d.N + 63) / 64, (d.M + 63) / 64, n2};
             g_last_stat_tiles = 0;
-            if (d.sbk == 1)
-                PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<true>), dim3((unsigned)(wg1 + wg2)), dim3(256), 0, cx.stream, p1, p2);
-            else
-                PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<false>), dim3((unsigned)(wg1 + wg2)), dim3(256), 0, cx.stream, p1, p2);
+            const dim3 grid((unsigned)(wg1 + wg2));
+            if (d.sbk == 1 && wide) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<true, 64>), grid, dim3(256), 0, cx.stream, p1, p2);
+            else if (d.sbk == 1) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<true, 32>), grid, dim3(256), 0, cx.stream, p1, p2);
+            else if (wide) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<false, 64>), grid, dim3(256), 0, cx.stream, p1, p2);
+            else PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<false, 32>), grid, dim3(256), 0, cx.stream, p1, p2);
             if (n1 > 1) gemm_finish_split(cx, w, g1, n1);                 // deferred: its region is now taken
             if (n2 > 1) gemm_finish_split(cx, d, g2, n2);                 // reduced at once (from behind that region)
             return;
