@@ -781,22 +781,34 @@ __global__ __launch_bounds__(256) void k_tr_dw_fwd(const float* __restrict__ X, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const float4 q = coef[c + j]; sc[j] = q.x; sh[j] = q.y; }
     }
+    // Straight-line code: all nine window loads are issued back to back from clamped (always valid) addresses and an
+    // out-of-map tap is switched off through its WEIGHT.  (The first version skipped such taps with `continue`: nine
+    // basic blocks, each load waited for before the next was issued -- block1's 84 MB took 46 us.)
+    const float* xb = X + (size_t)b * ih * iw * C + c;
+    float4 v[9], k[9];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         const int yy = (int)y * S - 1 + dy;
-        if ((unsigned)yy >= (unsigned)ih) continue;
+        const bool yok = (unsigned)yy < (unsigned)ih;
+        const int yc = yok ? yy : 0;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int xx = (int)x * S - 1 + dx;
-            if ((unsigned)xx >= (unsigned)iw) continue;
-            float4 v = *reinterpret_cast<const float4*>(X + (((size_t)b * ih + yy) * iw + xx) * C + c);
-            if (bn) {
-                v.x = fmaxf(fmaf(v.x, sc[0], sh[0]), 0.f); v.y = fmaxf(fmaf(v.y, sc[1], sh[1]), 0.f);
-                v.z = fmaxf(fmaf(v.z, sc[2], sh[2]), 0.f); v.w = fmaxf(fmaf(v.w, sc[3], sh[3]), 0.f);
-            }
-            const float4 k = *reinterpret_cast<const float4*>(w + (size_t)(dy * 3 + dx) * C + c);
-            o.x = fmaf(v.x, k.x, o.x); o.y = fmaf(v.y, k.y, o.y); o.z = fmaf(v.z, k.z, o.z); o.w = fmaf(v.w, k.w, o.w);
+            const bool ok = yok & ((unsigned)xx < (unsigned)iw);
+            const int xc = ((unsigned)xx < (unsigned)iw) ? xx : 0;
+            v[dy * 3 + dx] = *reinterpret_cast<const float4*>(xb + ((size_t)yc * iw + xc) * C);
+            const float4 kk = *reinterpret_cast<const float4*>(w + (size_t)(dy * 3 + dx) * C + c);
+            k[dy * 3 + dx] = ok ? kk : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float4 a = v[t];
+        if (bn) {
+            a.x = fmaxf(fmaf(a.x, sc[0], sh[0]), 0.f); a.y = fmaxf(fmaf(a.y, sc[1], sh[1]), 0.f);
+            a.z = fmaxf(fmaf(a.z, sc[2], sh[2]), 0.f); a.w = fmaxf(fmaf(a.w, sc[3], sh[3]), 0.f);
+        }
+        o.x = fmaf(a.x, k[t].x, o.x); o.y = fmaf(a.y, k[t].y, o.y); o.z = fmaf(a.z, k[t].z, o.z); o.w = fmaf(a.w, k[t].w, o.w);
     }
     *reinterpret_cast<float4*>(D + (size_t)i * 4) = o;        // D is [pixel][C]: element (pixel, quad) is at i * 4
 }
@@ -1125,21 +1137,30 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd(const float* __restrict__ dD,
             zh[j] = fmaf(zz[j], cf[j].z, cf[j].w);
         }
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        // straight-line window: nine unconditional loads from clamped offsets, an out-of-map tap multiplied by zero
+        // (with a branch per tap every load was waited for before the next one was issued)
+        float4 v[9];
+        float m[9];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int oy = y + 1 - dy;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int ox = x + 1 - dx;
-                if ((unsigned)oy < (unsigned)h && (unsigned)ox < (unsigned)wd) {
-                    // the output pixel (oy, ox) of the same frame: p + (1 - dy) * wd + (1 - dx)
-                    const float4 v = *reinterpret_cast<const float4*>(dD + (size_t)(p + (1 - dy) * wd + (1 - dx)) * C + 4 * q);
-                    const float4 k = *reinterpret_cast<const float4*>(w + (size_t)(dy * 3 + dx) * C + 4 * q);
-                    o.x = fmaf(v.x, k.x, o.x); o.y = fmaf(v.y, k.y, o.y); o.z = fmaf(v.z, k.z, o.z); o.w = fmaf(v.w, k.w, o.w);
-                    float4& a = acc[dy * 3 + dx];
-                    a.x = fmaf(xa[0], v.x, a.x); a.y = fmaf(xa[1], v.y, a.y); a.z = fmaf(xa[2], v.z, a.z); a.w = fmaf(xa[3], v.w, a.w);
-                }
+                const bool ok = ((unsigned)oy < (unsigned)h) & ((unsigned)ox < (unsigned)wd);
+                // the output pixel (oy, ox) of the same frame: p + (1 - dy) * wd + (1 - dx)
+                const int off = ok ? (1 - dy) * wd + (1 - dx) : 0;
+                v[dy * 3 + dx] = *reinterpret_cast<const float4*>(dD + (size_t)(p + off) * C + 4 * q);
+                m[dy * 3 + dx] = ok ? 1.f : 0.f;
             }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4 k = *reinterpret_cast<const float4*>(w + (size_t)t * C + 4 * q);
+            const float4 u = make_float4(v[t].x * m[t], v[t].y * m[t], v[t].z * m[t], v[t].w * m[t]);
+            o.x = fmaf(u.x, k.x, o.x); o.y = fmaf(u.y, k.y, o.y); o.z = fmaf(u.z, k.z, o.z); o.w = fmaf(u.w, k.w, o.w);
+            float4& a = acc[t];
+            a.x = fmaf(xa[0], u.x, a.x); a.y = fmaf(xa[1], u.y, a.y); a.z = fmaf(xa[2], u.z, a.z); a.w = fmaf(xa[3], u.w, a.w);
         }
         *reinterpret_cast<float4*>(dX + (size_t)p * C + 4 * q) = o;
         const float g0 = (xa[0] > 0.f) ? o.x : 0.f, g1 = (xa[1] > 0.f) ? o.y : 0.f;
@@ -1918,9 +1939,9 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                 // step's deferred-reduction launch, the two sum rows by the layer before's col_reduce)
                 const TrainLayerBuf& pb = cx.lbuf[i - 1];
                 const long n = (long)11 * l.cin;
-                // at most one resident round of workgroups (118 VGPRs: four waves per SIMD = four workgroups per CU);
+                // at most one resident round of workgroups (179 VGPRs with the nine window loads in flight: two per CU);
                 // 1 280 workgroups on 1 024 slots ran a quarter-filled second round
-                const int nblk = std::min(TR_NPART, 1024);
+                const int nblk = std::min(TR_NPART, 512);
                 if (g_arena_used + (long)nblk * n > cx.gemm_part_floats) return PP_ERR_UNSUPPORTED;
                 float* region = cx.gemm_part + g_arena_used;
                 PP_LAUNCH("k_tr_dw_bwd", k_tr_dw_bwd, dim3(nblk), dim3(256), 0, cx.stream, (const float*)cx.dD,
