@@ -827,22 +827,29 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd_in(const float* __restrict__ 
     divmod32(p, dih, b, uyy);
     const int c = (int)cq * 4, xx = (int)uxx, yy = (int)uyy;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    // straight-line: nine unconditional loads from clamped addresses, a tap without an output pixel multiplied by zero
+    const float* db = dD + (size_t)b * oh * ow * C + c;
+    float4 v[9];
+    float m[9];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         const int ty = yy + 1 - dy;
-        if (ty < 0 || (S == 2 && (ty & 1))) continue;        // S is 1 or 2 (train_step checks)
-        const int y = (S == 2) ? (ty >> 1) : ty;
-        if (y >= oh) continue;
+        const int y = (S == 2) ? (ty >> 1) : ty;             // S is 1 or 2 (train_step checks)
+        const bool yok = (ty >= 0) & !(S == 2 && (ty & 1)) & (y < oh);
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int tx = xx + 1 - dx;
-            if (tx < 0 || (S == 2 && (tx & 1))) continue;
             const int x = (S == 2) ? (tx >> 1) : tx;
-            if (x >= ow) continue;
-            const float4 v = *reinterpret_cast<const float4*>(dD + (((size_t)b * oh + y) * ow + x) * C + c);
-            const float4 k = *reinterpret_cast<const float4*>(w + (size_t)(dy * 3 + dx) * C + c);
-            o.x = fmaf(v.x, k.x, o.x); o.y = fmaf(v.y, k.y, o.y); o.z = fmaf(v.z, k.z, o.z); o.w = fmaf(v.w, k.w, o.w);
+            const bool ok = yok & (tx >= 0) & !(S == 2 && (tx & 1)) & (x < ow);
+            v[dy * 3 + dx] = *reinterpret_cast<const float4*>(db + ((size_t)(ok ? y : 0) * ow + (ok ? x : 0)) * C);
+            m[dy * 3 + dx] = ok ? 1.f : 0.f;
         }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 k = *reinterpret_cast<const float4*>(w + (size_t)t * C + c);
+        o.x = fmaf(v[t].x * m[t], k.x, o.x); o.y = fmaf(v[t].y * m[t], k.y, o.y);
+        o.z = fmaf(v[t].z * m[t], k.z, o.z); o.w = fmaf(v[t].w * m[t], k.w, o.w);
     }
     float4* dst = reinterpret_cast<float4*>(dX + (size_t)i * 4);
     if (accumulate) { const float4 q = *dst; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
@@ -879,18 +886,26 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd_w(const float* __restrict__ X
     }
     for (long p = p0 + ps; p < p1; p += nps) {
         const float4 g = *reinterpret_cast<const float4*>(dD + (size_t)p * C + 4 * q);
+        // straight-line window (as k_tr_dw_fwd): unconditional loads from clamped addresses, out-of-map taps times zero
+        const float* xb = X + (size_t)b * ih * iw * C + 4 * q;
+        float4 v[9];
+        float m[9];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int yy = y * S - 1 + dy;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int xx = x * S - 1 + dx;
-                if ((unsigned)yy < (unsigned)ih && (unsigned)xx < (unsigned)iw) {
-                    const float4 v = *reinterpret_cast<const float4*>(X + (((size_t)b * ih + yy) * iw + xx) * C + 4 * q);
-                    float4& a = acc[dy * 3 + dx];
-                    a.x = fmaf(v.x, g.x, a.x); a.y = fmaf(v.y, g.y, a.y); a.z = fmaf(v.z, g.z, a.z); a.w = fmaf(v.w, g.w, a.w);
-                }
+                const bool ok = ((unsigned)yy < (unsigned)ih) & ((unsigned)xx < (unsigned)iw);
+                v[dy * 3 + dx] = *reinterpret_cast<const float4*>(xb + ((size_t)(ok ? yy : 0) * iw + (ok ? xx : 0)) * C);
+                m[dy * 3 + dx] = ok ? 1.f : 0.f;
             }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float4& a = acc[t];
+            a.x = fmaf(v[t].x * m[t], g.x, a.x); a.y = fmaf(v[t].y * m[t], g.y, a.y);
+            a.z = fmaf(v[t].z * m[t], g.z, a.z); a.w = fmaf(v[t].w * m[t], g.w, a.w);
         }
         x += nps;
         while (x >= ow) { x -= ow; if (++y == oh) { y = 0; ++b; } }
@@ -1958,16 +1973,17 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
             if (X == nullptr) return PP_ERR_UNSUPPORTED;
             {   // partial rows [TR_NPART][9][cin] in a region of their own, added by the step's deferred-reduction launch
                 const long n = (long)9 * l.cin;
+                const int nbw = std::min(TR_NPART, 1024);       // (98 VGPRs: four workgroups per CU -- one resident round)
                 float* region = cx.part;
-                const bool room = g_arena_used + (long)TR_NPART * n <= cx.gemm_part_floats;
+                const bool room = g_arena_used + (long)nbw * n <= cx.gemm_part_floats;
                 if (room) region = cx.gemm_part + g_arena_used;
-                PP_LAUNCH("k_tr_dw_bwd_w", k_tr_dw_bwd_w, dim3(TR_NPART), dim3(256), 0, cx.stream, X, (const float*)cx.dD, region, B,
+                PP_LAUNCH("k_tr_dw_bwd_w", k_tr_dw_bwd_w, dim3(nbw), dim3(256), 0, cx.stream, X, (const float*)cx.dD, region, B,
                           l.in_h, l.in_w, l.out_h, l.out_w, l.cin, l.stride);
                 if (room) {
-                    g_jobs.push_back(ReduceJob{region, L.g(pre + "/depthwise_kernel"), n, n, 0L, TR_NPART, 0, 0, 1.0f});
-                    g_arena_used += ((long)TR_NPART * n + 63) / 64 * 64;
+                    g_jobs.push_back(ReduceJob{region, L.g(pre + "/depthwise_kernel"), n, n, 0L, nbw, 0, 0, 1.0f});
+                    g_arena_used += ((long)nbw * n + 63) / 64 * 64;
                 } else {
-                    tr_reduce(cx.stream, (const float*)cx.part, TR_NPART, n, n, L.g(pre + "/depthwise_kernel"), 0L, 0, 0, 1.0f);
+                    tr_reduce(cx.stream, (const float*)cx.part, nbw, n, n, L.g(pre + "/depthwise_kernel"), 0L, 0, 0, 1.0f);
                 }
             }
             // gradient of this layer's input: the previous layer's dA, the previous block's output gradient, or the canvas
