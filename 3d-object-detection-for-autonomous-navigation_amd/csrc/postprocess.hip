@@ -342,7 +342,11 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         }
         if (lane < nk) s_keep[lane] = k0;
         if (lane + 64 < nk) s_keep[lane + 64] = k1;
-        if (lane == 0) { s_nkeep = nk; p.n_dets[b] = nk; }
+        if (lane == 0) {
+            s_nkeep = nk;
+            p.n_dets[b] = nk;
+            if (p.n_dets_host != nullptr) p.n_dets_host[b] = nk;
+        }
     }
     __syncthreads();
     P_STAMP()   // sweep
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     const int nk = s_nkeep;
     if (tid < nk) {
         const int i = s_keep[tid];
-        pp_detection* o = p.dets + (size_t)b * p.post_max + tid;
+        pp_detection d;
         float r = s_box[i][6];
         // model/voxelnet.py:1297-1310: the flip exists only with use_direction_classifier
         const bool opp = p.use_dir && ((r > 0.f) != (s_dir[i] == 1));
@@ -360,20 +364,22 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         const double x = s_box[i][0], y = s_box[i][1], z = s_box[i][2];
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            o->box3d_camera[q] = x * (double)M[q * 4 + 0] + y * (double)M[q * 4 + 1] + z * (double)M[q * 4 + 2] +
-                                 (double)M[q * 4 + 3];
-        o->box3d_camera[3] = (double)s_box[i][4];  // l
-        o->box3d_camera[4] = (double)s_box[i][5];  // h
-        o->box3d_camera[5] = (double)s_box[i][3];  // w
-        o->box3d_camera[6] = (double)r;
+            d.box3d_camera[q] = x * (double)M[q * 4 + 0] + y * (double)M[q * 4 + 1] + z * (double)M[q * 4 + 2] +
+                                (double)M[q * 4 + 3];
+        d.box3d_camera[3] = (double)s_box[i][4];  // l
+        d.box3d_camera[4] = (double)s_box[i][5];  // h
+        d.box3d_camera[5] = (double)s_box[i][3];  // w
+        d.box3d_camera[6] = (double)r;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) o->box3d_lidar[q] = s_box[i][q];
-        o->box3d_lidar[6] = r;
-        o->score = s_score[i];
-        o->label = s_label[i];
-        o->dir_label = s_dir[i];
-        o->anchor_index = s_anchor[i];
-        o->reserved = 0;
+        for (int q = 0; q < 6; ++q) d.box3d_lidar[q] = s_box[i][q];
+        d.box3d_lidar[6] = r;
+        d.score = s_score[i];
+        d.label = s_label[i];
+        d.dir_label = s_dir[i];
+        d.anchor_index = s_anchor[i];
+        d.reserved = 0;
+        p.dets[(size_t)b * p.post_max + tid] = d;
+        if (p.dets_host != nullptr) p.dets_host[(size_t)b * p.post_max + tid] = d;
     }
 #ifdef PP_POST_STAMPS
     __syncthreads();

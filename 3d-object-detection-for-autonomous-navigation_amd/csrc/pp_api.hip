@@ -493,12 +493,14 @@ int run_backbone(pp_engine* e, int batch) {
     return PP_OK;
 }
 
-int run_post(pp_engine* e, int batch) {
+// to_host: the kernel also fills the page-locked result buffers (the fused path: no copy nodes behind it)
+int run_post(pp_engine* e, int batch, bool to_host = false) {
     PostParams p;
     p.batch = batch; p.A = e->A; p.pre_max = e->cfg.nms_pre_max_size; p.post_max = e->cfg.nms_post_max_size;
     p.score_thr = e->cfg.nms_score_threshold; p.iou_thr = e->cfg.nms_iou_threshold;
     p.head = e->d_head; p.cls = e->cls_plane_live ? e->d_cls : nullptr; p.napl = e->napl; p.ncls = e->ncls; p.use_dir = e->use_dir ? 1 : 0; p.mask = e->d_mask; p.anchors = e->d_anchors;
     p.calib = e->d_calib; p.dets = e->d_dets; p.n_dets = e->d_ndets;
+    p.dets_host = to_host ? e->h_dets : nullptr; p.n_dets_host = to_host ? e->h_ndets : nullptr;
     ProfScope ps(e, "k_postprocess");
     launch_postprocess(p, e->stream);
     HIPCHK(e, hipGetLastError());
@@ -1187,9 +1189,15 @@ static int enqueue_detect(pp_engine* e, int B, int max_n) {
     if ((st = run_pfn(e, B, false, nullptr, true))) return st;
     if (!e->mask_in_pfn && (st = run_anchor_mask(e, B))) return st;
     if ((st = run_backbone(e, B))) return st;
-    if ((st = run_post(e, B))) return st;
-    HIPCHK(e, hipMemcpyAsync(e->h_dets, e->d_dets, (size_t)B * e->cfg.nms_post_max_size * sizeof(pp_detection), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->h_ndets, e->d_ndets, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    // the post-process stores its few kept detections per frame straight into the page-locked result buffers (PP_POST_COPY=1:
+    // the two device-to-host copy nodes of rounds 1-3 instead)
+    static int post_copy = -1;
+    if (post_copy < 0) { const char* s = getenv("PP_POST_COPY"); post_copy = (s && s[0] == '1') ? 1 : 0; }
+    if ((st = run_post(e, B, post_copy == 0))) return st;
+    if (post_copy) {
+        HIPCHK(e, hipMemcpyAsync(e->h_dets, e->d_dets, (size_t)B * e->cfg.nms_post_max_size * sizeof(pp_detection), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->h_ndets, e->d_ndets, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    }
     return PP_OK;
 }
 
@@ -1279,7 +1287,13 @@ int pp_get_detections(pp_handle e, pp_detection* dets, int32_t* n_dets) {
     if (B < 1) return fail(e, PP_ERR_STATE, "pp_get_detections: no pp_detect_async results on this handle (or a stage call has reused the buffers)");
     (void)hipSetDevice(e->device);
     HIPCHK(e, hipStreamSynchronize(e->stream));   // immediate after pp_sync; never hands out a half-written buffer
-    memcpy(dets, e->h_dets, (size_t)B * e->cfg.nms_post_max_size * sizeof(pp_detection));
+    // the kept detections of every frame, zeros behind them (the kernel writes only what it keeps)
+    const size_t pm = (size_t)e->cfg.nms_post_max_size;
+    for (int b = 0; b < B; ++b) {
+        size_t n = (size_t)std::max(0, std::min(e->h_ndets[b], (int)pm));
+        memcpy(dets + (size_t)b * pm, e->h_dets + (size_t)b * pm, n * sizeof(pp_detection));
+        memset(dets + (size_t)b * pm + n, 0, (pm - n) * sizeof(pp_detection));
+    }
     memcpy(n_dets, e->h_ndets, (size_t)B * sizeof(int));
     return PP_OK;
 }

@@ -187,6 +187,10 @@ struct PostParams {
     const float* calib;    // [batch][16]  rect @ Trv2c (float32)
     pp_detection* dets;    // [batch][post_max]
     int* n_dets;           // [batch]
+    // page-locked host copies the kernel fills itself (or NULL): the kept detections of a frame are a few hundred
+    // bytes -- stored straight over the host link they replace two copy nodes (9 us of a replayed step)
+    pp_detection* dets_host;
+    int* n_dets_host;
 };
 void launch_postprocess(const PostParams& p, hipStream_t s);
 
