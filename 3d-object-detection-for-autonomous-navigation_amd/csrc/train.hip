@@ -720,7 +720,9 @@ static void tr_gemm_pair(const TrainCtx& cx, const GemmCall& w, const GemmCall& 
 // weight gradients: K = rows (pixels); enough slices to fill the chip, bounded by the partial buffer
 static int wgrad_split(const TrainCtx& cx, int M, int N, int K) {
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-    long want = std::max<long>(1, 1024 / tiles);
+    static long wgs = -1;      // PP_TRAIN_WGRAD_WGS: workgroups a weight-gradient product is cut into
+    if (wgs < 0) { const char* e = getenv("PP_TRAIN_WGRAD_WGS"); wgs = e ? atol(e) : 1024; }
+    long want = std::max<long>(1, wgs / tiles);
     want = std::min<long>(want, (K + 255) / 256);
     while (want > 1 && want * (long)M * N > cx.gemm_part_floats) --want;
     return (int)want;
