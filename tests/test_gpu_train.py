@@ -104,6 +104,40 @@ def test_gradients_match_autograd_small_grids(pp, hip_lib, name):
     tr.close()
 
 
+def test_large_batch_paths_match_the_two_frame_step(pp, hip_lib):
+    """The kernels a full-chip batch selects -- 64 x 64 product tiles with 32-wide chunks, weight- and input-gradient
+    products paired in one launch, a workgroup per output in the column sums and the BatchNorm finalise (> 1 000 partial
+    rows), the persistent reductions capped at one resident round of workgroups -- against the two-frame step the
+    autograd tests pin, through a size-independent property: a batch made of 256 copies of a 2-frame batch has the
+    2-frame batch's BatchNorm statistics and (the losses being batch means) its gradients.  Bar: 1e-4 of a tensor's
+    largest gradient (different summation orders over 256 x the rows; measured 3.4e-6)."""
+    cfg2 = _variant(pp, "wide", 2)
+    d = pp.config.Derived(cfg2)
+    rng = np.random.default_rng(5)
+    frames = [rng.uniform([0, -0.64, -3], [1.6, 0.64, 3], (n, 3)).astype(np.float32) for n in (900, 400)]
+    d, labels, reg = _problem(pp, cfg2, frames, 13)
+    w = pp.weights.init_weights(d, seed=23)
+    tr = pp.Trainer(cfg2, w, max_batch=2, max_points_per_frame=4096)
+    out2 = tr.forward_backward(frames, labels, reg)
+    g2 = tr.gradients()
+    tr.close()
+    copies = 256
+    B = 2 * copies
+    cfgB = _variant(pp, "wide", B)
+    trb = pp.Trainer(cfgB, w, max_batch=B, max_points_per_frame=4096)
+    outb = trb.forward_backward(frames * copies, np.tile(labels, (copies, 1)), np.tile(reg, (copies, 1, 1)))
+    for k in ("loss", "loc_loss_reduced", "cls_loss_reduced", "dir_loss_reduced"):
+        assert abs(outb[k] - out2[k]) <= 2e-5 * max(1.0, abs(out2[k])), (k, outb[k], out2[k])
+    (wn, wmax), (ln, l2) = _rel_errors(trb.gradients(), g2)
+    print(f"B={B} (256 copies) vs B=2: worst relative gradient difference {wmax:.2e} ({wn}), L2 {l2:.2e} ({ln})")
+    assert wmax <= 1e-4, (wn, wmax)
+    # and bit-reproducible at this size too
+    gb = trb.grads.cpu().numpy().copy()
+    outb2 = trb.forward_backward(frames * copies, np.tile(labels, (copies, 1)), np.tile(reg, (copies, 1, 1)))
+    assert outb2["loss"] == outb["loss"] and np.array_equal(trb.grads.cpu().numpy(), gb)
+    trb.close()
+
+
 def test_gradients_shipped_config_batch2(pp, hip_lib):
     """cfg-A at B=2 (the reference's training batch, configs/train.yaml:62; 1.1 M trainable parameters).  With the
     synthetic random-initialised weights this problem is ill-conditioned in float32: torch's OWN float32 autograd
