@@ -1933,6 +1933,13 @@ int pp_train_step(pp_handle e, const float* params_dev, float* grads_dev, float*
     return pp_train_step_wait(e, losses);
 }
 
+int pp_stream(pp_handle e, void** stream) {
+    if (!e) return PP_ERR_ARG;
+    if (!stream) return fail(e, PP_ERR_ARG, "pp_stream: stream is NULL");
+    *stream = (void*)e->stream;
+    return PP_OK;
+}
+
 int pp_train_graph_stats(pp_handle e, int32_t* captures, int32_t* replays) {
     if (!e) return PP_ERR_ARG;
     if (captures) *captures = e->train ? e->train->n_captures : 0;

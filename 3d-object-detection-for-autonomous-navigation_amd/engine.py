@@ -444,6 +444,12 @@ class Engine:
         """A page-locked numpy array (PinnedArray) for targets / frames the loader fills in place."""
         return PinnedArray(self._lib, shape, dtype)
 
+    def stream_ptr(self):
+        """The handle's HIP stream as an integer (pp_stream): device work enqueued on it runs behind the handle's own."""
+        p = ctypes.c_void_p(0)
+        self._check(self._lib.pp_stream(self._h, ctypes.byref(p)), "pp_stream")
+        return int(p.value or 0)
+
     @staticmethod
     def _loss_dict(losses):
         return {"loss": float(losses[0]), "loc_loss_reduced": float(losses[1]), "cls_loss_reduced": float(losses[2]),

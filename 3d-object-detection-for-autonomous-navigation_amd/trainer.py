@@ -36,6 +36,7 @@ class Trainer:
         self.torch = torch
         self.engine = Engine(config, max_batch=max_batch, max_points_per_frame=max_points_per_frame, device=device)
         self._prefetched = None      # the TrainBatch whose points are already on their way (forward_backward(prefetch=))
+        self._ext_stream = None      # torch.cuda.ExternalStream over the engine's stream (_engine_stream)
         d = self.engine.d
         self.layout, n_params, n_state = self.engine.train_layout()
         self.device = torch.device("cuda", device)
@@ -113,11 +114,8 @@ class Trainer:
         st.reg_targets[...] = np.asarray(reg_targets, dtype=np.float32).reshape(B, d.num_anchors, 7)
         return st
 
-    def forward_backward(self, frames, labels=None, reg_targets=None, prefetch=None):
-        """frames: a list of clouds with labels / reg_targets, or one TrainBatch from stage().
-        prefetch: the TrainBatch of the NEXT step -- its points go to the GPU (the handle's other input buffer, the copy
-        stream) while this step's kernels run, the loader's hand-over of train.py:228-304; pass that same batch as
-        `frames` of the next call."""
+    def _launch(self, frames, labels, reg_targets, prefetch):
+        """Enqueue the step (and the upload of the next batch beside it); the caller waits with engine.train_step_wait()."""
         if isinstance(frames, TrainBatch):
             tb = frames
             if self._prefetched is not tb:
@@ -128,25 +126,44 @@ class Trainer:
             if isinstance(prefetch, TrainBatch):
                 self.engine.upload_async(prefetch.points)
                 self._prefetched = prefetch
-            return self.engine.train_step_wait()
+            return
         self._prefetched = None
         self.engine.upload(frames)
-        return self.engine.train_step(self.params.data_ptr(), self.grads.data_ptr(), self.state.data_ptr(), labels,
-                                      reg_targets)
+        self.engine.train_step_async(self.params.data_ptr(), self.grads.data_ptr(), self.state.data_ptr(), labels, reg_targets)
+
+    def forward_backward(self, frames, labels=None, reg_targets=None, prefetch=None):
+        """frames: a list of clouds with labels / reg_targets, or one TrainBatch from stage().
+        prefetch: the TrainBatch of the NEXT step -- its points go to the GPU (the handle's other input buffer, the copy
+        stream) while this step's kernels run, the loader's hand-over of train.py:228-304; pass that same batch as
+        `frames` of the next call."""
+        self._launch(frames, labels, reg_targets, prefetch)
+        return self.engine.train_step_wait()
+
+    def _engine_stream(self):
+        """torch's view of the engine's own stream: the all-reduce and the AdamW kernel are enqueued THERE, behind the
+        backward pass, so nothing needs a host round trip between trainStep's halves (and nothing can overtake)."""
+        if self._ext_stream is None:
+            self._ext_stream = self.torch.cuda.ExternalStream(self.engine.stream_ptr(), device=self.device)
+        return self._ext_stream
+
+    def _enqueue_update(self, dist):
+        with self.torch.cuda.stream(self._engine_stream()):
+            optim.allreduce_gradients(self.grads, dist)        # one collective per step over the flat buffer
+            self.optimizer.apply_gradients(self.grads)
 
     def apply_gradients(self, dist=None):
         """optimizer.apply_gradients (train.py:301) after the data-parallel mean of the flat gradient buffer.  The
-        all-reduce and the AdamW kernel run on torch's current stream, the next pp_train_step on the engine's own
-        (non-blocking) stream: this returns only when both are through, so the next step can neither overwrite
-        gradients that are still being reduced nor read half-updated parameters."""
-        optim.allreduce_gradients(self.grads, dist)        # one collective per step over the flat buffer
-        self.optimizer.apply_gradients(self.grads)
-        self.torch.cuda.current_stream(self.device).synchronize()
+        all-reduce and the AdamW kernel run on the engine's stream (behind the step that produced the gradients); this
+        returns when both are through, so a caller may read the parameters."""
+        self._enqueue_update(dist)
+        self._engine_stream().synchronize()
 
     def step(self, frames, labels=None, reg_targets=None, dist=None, prefetch=None):
-        out = self.forward_backward(frames, labels, reg_targets, prefetch=prefetch)
-        self.apply_gradients(dist)
-        return out
+        """One optimizer step: forward + loss + backward, gradient exchange, AdamW -- enqueued back to back on the engine's
+        stream, ONE host wait at the end."""
+        self._launch(frames, labels, reg_targets, prefetch)
+        self._enqueue_update(dist)
+        return self.engine.train_step_wait()
 
     def close(self):
         self.engine.close()

@@ -312,6 +312,11 @@ int pp_train_step_async(pp_handle h, const float* params_dev, float* grads_dev, 
                         const float* reg_targets, int32_t batch, const pp_loss_config* cfg);
 int pp_train_step_wait(pp_handle h, float* losses);
 
+/* The handle's HIP stream (hipStream_t as void*).  A caller that enqueues its own device work behind a pp_train_step_async
+ * -- the gradient all-reduce and pp_adamw_step_device of the optimizer step (train.py:301) -- does it on this stream and
+ * needs no host synchronisation in between: pp_train_step_wait then waits for that work too. */
+int pp_stream(pp_handle h, void** stream);
+
 /* How often pp_train_step captured a hipGraph and how often it replayed one (one graph per input buffer of the
  * handle): steady-state steps must replay -- a regression check, not part of the reference's surface. */
 int pp_train_graph_stats(pp_handle h, int32_t* captures, int32_t* replays);
