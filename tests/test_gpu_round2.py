@@ -582,3 +582,32 @@ def test_deconv_r_unit_runs_at_odd_batches(pp, hip_lib, B):
         np.testing.assert_allclose(imb[k][B - 1], ref["preds"][k][0], rtol=0, atol=TOL, err_msg=k)
     big.close()
     one.close()
+
+
+def test_results_written_by_the_post_process_itself(pp, hip_lib):
+    """Round 3: k_postprocess stores a frame's kept detections straight into the page-locked result buffers (no copy
+    nodes behind the fused path).  What the host reads must be the kept entries and zeros behind them -- also when the
+    pass before left MORE detections in the same frame slot -- and a second handle running the same frames must agree."""
+    cfg = pp.config.pedestrian_d435i_config(4)
+    d = pp.config.Derived(cfg)
+    w = pp.weights.init_weights(d, seed=7)
+    eng = pp.Engine(cfg, max_batch=4, max_points_per_frame=20000)
+    eng.load_weights(w)
+    rich = [pp.synth.d435i_cloud(40 + i, 16384) for i in range(4)]
+    poor = [pp.synth.d435i_cloud(60 + i, 16384)[:300] for i in range(4)]      # a few hundred points: fewer boxes kept
+    d1, n1 = eng.detect(rich)
+    d1, n1 = d1.copy(), n1.copy()
+    d2, n2 = eng.detect(poor)
+    assert (n2 <= n1).all() and (n2 < n1).any(), (n1, n2)
+    zero = np.zeros((), dtype=d2.dtype)
+    for b in range(4):
+        assert (d2[b, n2[b]:] == zero).all(), "entries behind the kept detections must read as zeros"
+    d3, n3 = eng.detect(rich)
+    assert np.array_equal(n3, n1) and all(np.array_equal(d3[b, :n1[b]], d1[b, :n1[b]]) for b in range(4))
+    other = pp.Engine(cfg, max_batch=4, max_points_per_frame=20000)
+    other.load_weights(w)
+    d4, n4 = other.detect(poor)
+    assert np.array_equal(n4, n2) and all(np.array_equal(d4[b, :n2[b]], d2[b, :n2[b]]) for b in range(4))
+    other.close()
+    eng.close()
+

@@ -315,4 +315,15 @@ def test_voxelnet_training_call_surface(pp, hip_lib):
     assert np.abs(net.trainer.params.cpu().numpy() - before).max() > 0
     with pytest.raises(ValueError):
         net(ex[0], ex[1], ex[2], ex[6])
+    # the two halves of pp_train_step: a second launch before the wait, or a wait without a launch, is an error
+    tr = net.trainer
+    eng = tr.engine
+    eng.upload(frames)
+    eng.train_step_async(tr.params.data_ptr(), tr.grads.data_ptr(), tr.state.data_ptr(), labels, reg)
+    with pytest.raises(RuntimeError):
+        eng.train_step_async(tr.params.data_ptr(), tr.grads.data_ptr(), tr.state.data_ptr(), labels, reg)
+    assert eng.train_step_wait()["loss"] > 0
+    with pytest.raises(RuntimeError):
+        eng.train_step_wait()
+    assert eng.stream_ptr() != 0
     net.trainer.close()
