@@ -83,8 +83,10 @@ void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, c
     if (batch <= 0) return;
     static int fused = -1;      // PP_ANCHOR_MASK_FUSED=0: the three-kernel path everywhere (A/B measurements)
     if (fused < 0) { const char* e = getenv("PP_ANCHOR_MASK_FUSED"); fused = (e && e[0] == '0') ? 0 : 1; }
-    // one workgroup per frame: the latency case (few frames); many frames keep the chip-wide kernels
-    if (fused && ny * (nx | 1) <= AM_MAX_CELLS && batch <= 8) {
+    // one workgroup per frame whenever the grid fits the LDS image; larger grids keep the three chip-wide kernels
+    static int maxb = -1;       // PP_ANCHOR_MASK_FUSED_MAXB: largest batch of the one-workgroup-per-frame kernel
+    if (maxb < 0) { const char* e = getenv("PP_ANCHOR_MASK_FUSED_MAXB"); maxb = e ? atoi(e) : (1 << 30); }   // (8 until round 3: at B=64 one launch of 64 workgroups instead of three chip-wide ones is 0-1 % more frames/s)
+    if (fused && ny * (nx | 1) <= AM_MAX_CELLS && batch <= maxb) {
         PP_LAUNCH("k_anchor_mask_frame", k_anchor_mask_frame, dim3(batch), dim3(1024), 0, s, cellmap, nz, ny, nx, cells, A,
                   threshold, mask);
         return;
