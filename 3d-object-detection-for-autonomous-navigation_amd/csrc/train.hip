@@ -569,6 +569,12 @@ static thread_local int g_last_stat_tiles = 0;
 // a launch with fewer workgroups than this lives on memory latency, not on throughput: 64-wide K chunks (half the
 // dependent load -> LDS -> MFMA rounds), and the two gradient products of a layer share one launch
 #define TR_LATENCY_WGS 512
+// PP_TRAIN_WIDE=0: 32-wide chunks everywhere (A/B measurements)
+static bool wide_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PP_TRAIN_WIDE"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 
 // C[M][N] (+)= A(m,k) * B(k,n) [+ bias(n)],  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
 // defer: a split-K product whose result only the optimizer reads (weight gradients) keeps its partial tiles in a
@@ -624,7 +630,7 @@ static void tr_gemm(const TrainCtx& cx, const GemmCall& c) {
         const bool akc = c.sak == 1, bkc = c.sbk == 1;
         int kper = ((K + ksplit - 1) / ksplit + 31) / 32 * 32;
         const long small = (long)((M + 63) / 64) * ((N + 63) / 64) * ((K + kper - 1) / kper);
-        const bool wide = small < TR_LATENCY_WGS;        // 64-wide chunks
+        const bool wide = small < TR_LATENCY_WGS && wide_enabled();        // 64-wide chunks
         if (wide) kper = (kper + 63) / 64 * 64;
         ksplit = (K + kper - 1) / kper;
         g.kper = kper;
@@ -683,7 +689,7 @@ static void tr_gemm_pair(const TrainCtx& cx, const GemmCall& w, const GemmCall& 
         int ksd;
         (void)gemm_args(cx, d, ksd);
         const auto tiles = [](const GemmCall& c) { return (long)((c.M + 63) / 64) * ((c.N + 63) / 64); };
-        const bool wide = tiles(w) * ks1 + tiles(d) * ksd < 2 * TR_LATENCY_WGS;
+        const bool wide = tiles(w) * ks1 + tiles(d) * ksd < 2 * TR_LATENCY_WGS && wide_enabled();
         const int kround = wide ? 64 : 32;
         auto plan = [kround](const GemmCall& c, int ks, int& kper, int& nks) {
             kper = ((c.K + ks - 1) / ks + kround - 1) / kround * kround;
