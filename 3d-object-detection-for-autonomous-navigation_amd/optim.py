@@ -12,6 +12,7 @@ The arithmetic of the update is in csrc/optim.hip; this module only holds the st
 """
 import ctypes
 import math
+import os
 
 
 class ExponentialDecay:
@@ -76,8 +77,10 @@ class AdamW:
 def allreduce_gradients(flat_grads, dist=None):
     """Mean of the flat gradient buffer over the ranks, in place; a single collective.  `dist` is
     torch.distributed (or None / uninitialised / world size 1: nothing to do)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return flat_grads
+    if dist.get_world_size() == 1 and os.environ.get("PP_FORCE_ALLREDUCE") != "1":
+        return flat_grads       # (PP_FORCE_ALLREDUCE=1: the one-rank rehearsal still sends the buffer through the backend)
     dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     flat_grads /= dist.get_world_size()
     return flat_grads

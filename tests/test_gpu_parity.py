@@ -505,6 +505,9 @@ def test_bench_one_rank_under_launcher_with_rccl(hip_lib):
     env = dict(os.environ)
     env.pop("PP_BENCH_DIST_BACKEND", None)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    # the gradient all-reduce of the training leg is skipped at world size 1 unless forced: here it goes through RCCL,
+    # enqueued -- as on a multi-GPU node -- on the engine's own stream (torch ExternalStream), behind the backward pass
+    env["PP_FORCE_ALLREDUCE"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29519", "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2",
            "--batch", "8", "--no-latency-b1", "--no-cfgk", "--no-cpu-baseline"]
