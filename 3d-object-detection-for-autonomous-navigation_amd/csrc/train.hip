@@ -13,11 +13,17 @@
 // device buffer owned by the caller (order: train_layout()), gradients go to a second flat buffer of the same
 // order -- what the AdamW kernel (optim.hip) and the data-parallel all-reduce consume.
 //   * the 1x1 convolutions, the transposed convolutions (kernel == stride: a GEMM per input pixel) and the heads
-//     run as float32 MFMA GEMMs (v_mfma_f32_32x32x2_f32), forward NN / NT, input gradients with the other
-//     operand transposed, weight gradients as split-K TN GEMMs (K = pixels) reduced in a fixed order;
-//   * depthwise 3x3, BatchNorm statistics / normalisation / backward, the PFN and the scatter are HBM-bound
-//     element kernels; every reduction goes through per-workgroup partial sums added in a fixed order, so a
-//     step is bit-reproducible (no floating-point atomics).
+//     run as products on the 16-bit matrix pipe with float32-equivalent results (k_tr_gemm2: three bfloat16 pieces
+//     per value, six piece products; k_tr_gemm on v_mfma_f32_32x32x2_f32 is the fallback for odd shapes), forward
+//     NN / NT, input gradients with the other operand transposed, weight gradients as split-K TN products (K =
+//     pixels) reduced in a fixed order; the two gradient products of a layer share a launch (k_tr_gemm2_pair);
+//   * the pre-BatchNorm map Z of a layer is what is kept: the activation of an in-block layer is never written --
+//     its readers (next depthwise, the backward kernels) evaluate relu(z * sc + sh) from Z and a per-channel
+//     coefficient table (k_tr_bn_finalize); the depthwise backward is one pass (k_tr_dw_bwd: input gradient, kernel
+//     gradient, and the BatchNorm-backward sums of the layer before); the PFN kernels keep a pillar's points in the
+//     lanes and recompute the ten-FMA Dense row instead of storing it;
+//   * every reduction goes through per-workgroup partial sums added in a fixed order, so a step is bit-reproducible
+//     (no floating-point atomics); persistent reduction grids never exceed one resident round of workgroups.
 // BatchNorm in training mode normalises with the batch mean and the biased batch variance; the moving
 // statistics are updated as Keras does (moving = moving * momentum + batch * (1 - momentum); the RPN's fused
 // BatchNorm feeds the unbiased variance, the PFN's rank-3 BatchNorm the biased one).  The PFN statistics run
