@@ -134,6 +134,7 @@ class Engine:
             msg = self._lib.pp_last_error(None)
             raise RuntimeError(f"pp_create failed ({_STATUS.get(st, st)}): {msg.decode() if msg else ''}")
         self._h = h
+        self._train_targets = None      # labels / regression targets of a step in flight (train_step_async)
         self._staged = collections.deque(maxlen=2)   # Stagings of the last two upload_async calls (see there)
         self.anchors = build_anchors(d)
         self.anchor_cells = build_anchor_cells(self.anchors, d)
