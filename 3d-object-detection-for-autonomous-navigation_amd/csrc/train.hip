@@ -828,6 +828,69 @@ __global__ __launch_bounds__(256) void k_tr_dw_fwd(const float* __restrict__ X, 
 }
 
 
+// The same layer with the nine tap vectors of a thread's channels in REGISTERS: a workgroup owns a contiguous range of
+// output pixels, a thread 4 channels of every (256 / (C / 4))-th pixel of the range (as the backward kernels).  Re-read
+// per output, the taps were half of k_tr_dw_fwd's traffic through the CU's vector-memory path (18 loads of 16 bytes per
+// 16 output bytes: block1's 84 MB took 30 us beside element kernels at 5-6 TB/s).
+__global__ __launch_bounds__(256) void k_tr_dw_fwd_p(const float* __restrict__ X, const float* __restrict__ w,
+                                                     float* __restrict__ D, int B, int ih, int iw, int oh, int ow, int C,
+                                                     int S, const float4* __restrict__ coef) {
+    const int tid = threadIdx.x;
+    const int cq = C >> 2;
+    const int q = tid % cq, ps = tid / cq, nps = 256 / cq;
+    const long npix = (long)B * oh * ow;
+    const long per = (npix + gridDim.x - 1) / gridDim.x;
+    const long p0 = (long)blockIdx.x * per, p1 = min(npix, p0 + per);
+    float4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const float4*>(w + (size_t)t * C + 4 * q);
+    const bool bn = coef != nullptr;                          // uniform
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float4 cfv = coef[4 * q + j]; sc[j] = cfv.x; sh[j] = cfv.y; }
+    }
+    int x = 0, y = 0, b = 0;
+    if (p0 + ps < p1) {
+        const unsigned up = (unsigned)(p0 + ps);             // pixel counts < 2^31 (launcher)
+        const unsigned qy = up / (unsigned)ow;
+        x = (int)(up - qy * (unsigned)ow);
+        b = (int)(qy / (unsigned)oh);
+        y = (int)(qy - (unsigned)b * (unsigned)oh);
+    }
+    for (long p = p0 + ps; p < p1; p += nps) {
+        const float* xb = X + (size_t)b * ih * iw * C + 4 * q;
+        float4 v[9];
+        float m[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y * S - 1 + dy;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = x * S - 1 + dx;
+                const bool ok = ((unsigned)yy < (unsigned)ih) & ((unsigned)xx < (unsigned)iw);
+                v[dy * 3 + dx] = *reinterpret_cast<const float4*>(xb + ((size_t)(ok ? yy : 0) * iw + (ok ? xx : 0)) * C);
+                m[dy * 3 + dx] = ok ? 1.f : 0.f;
+            }
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float4 a = v[t];
+            if (bn) {
+                a.x = fmaxf(fmaf(a.x, sc[0], sh[0]), 0.f); a.y = fmaxf(fmaf(a.y, sc[1], sh[1]), 0.f);
+                a.z = fmaxf(fmaf(a.z, sc[2], sh[2]), 0.f); a.w = fmaxf(fmaf(a.w, sc[3], sh[3]), 0.f);
+            }
+            // (an out-of-map tap: its weight times zero -- the same +0 terms as k_tr_dw_fwd's zeroed weights)
+            const float4 k = make_float4(wk[t].x * m[t], wk[t].y * m[t], wk[t].z * m[t], wk[t].w * m[t]);
+            o.x = fmaf(a.x, k.x, o.x); o.y = fmaf(a.y, k.y, o.y); o.z = fmaf(a.z, k.z, o.z); o.w = fmaf(a.w, k.w, o.w);
+        }
+        *reinterpret_cast<float4*>(D + (size_t)p * C + 4 * q) = o;
+        x += nps;
+        while (x >= ow) { x -= ow; if (++y == oh) { y = 0; ++b; } }
+    }
+}
+
 // gradient of the depthwise convolution with respect to its input:
 // dX[b,yy,xx,c] (+)= sum over taps with (yy+1-dy) % S == 0 ... of dD[b,(yy+1-dy)/S,(xx+1-dx)/S,c] * w[t][c]
 __global__ __launch_bounds__(256) void k_tr_dw_bwd_in(const float* __restrict__ dD, const float* __restrict__ w,
@@ -1149,6 +1212,11 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd(const float* __restrict__ dD,
     float4 cf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cf[j] = coefp[4 * q + j];
+    // the nine tap vectors of this thread's channels stay in registers for all its pixels (re-read per pixel they were
+    // half of the kernel's traffic through the CU's vector-memory path: 19 loads per 16 output bytes)
+    float4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const float4*>(w + (size_t)t * C + 4 * q);
     int x = 0, y = 0;
     if (p0 + ps < p1) {
         const unsigned up = (unsigned)(p0 + ps);             // pixel counts < 2^31 (launcher)
@@ -1185,7 +1253,7 @@ __global__ __launch_bounds__(256) void k_tr_dw_bwd(const float* __restrict__ dD,
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const float4 k = *reinterpret_cast<const float4*>(w + (size_t)t * C + 4 * q);
+            const float4 k = wk[t];
             const float4 u = make_float4(v[t].x * m[t], v[t].y * m[t], v[t].z * m[t], v[t].w * m[t]);
             o.x = fmaf(u.x, k.x, o.x); o.y = fmaf(u.y, k.y, o.y); o.z = fmaf(u.z, k.z, o.z); o.w = fmaf(u.w, k.w, o.w);
             float4& a = acc[t];
@@ -1852,10 +1920,21 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
         if (l.kind == LAYER_SEP) {
             const std::string pre = "rpn/block" + std::to_string(bi + 1) + "/" + std::to_string(li);
             const long rows = (long)B * l.out_h * l.out_w;
-            PP_LAUNCH("k_tr_dw_fwd", k_tr_dw_fwd, dim3(blocks_for(rows * (l.cin / 4))), dim3(256), 0, cx.stream, cur,
-                      L.p(pre + "/depthwise_kernel"), tb.D, (unsigned)(rows * (l.cin / 4)), l.in_h, l.in_w,
-                      make_div((unsigned)l.out_h), make_div((unsigned)l.out_w), make_div((unsigned)(l.cin / 4)), l.cin, l.stride,
-                      cur_coef);
+            static int dwp = -1;      // PP_TRAIN_DWFWD=0: the thread-per-output kernel everywhere (A/B measurements)
+            if (dwp < 0) { const char* e = getenv("PP_TRAIN_DWFWD"); dwp = (e && e[0] == '0') ? 0 : 1; }
+            const long nthr = rows * (l.cin / 4);
+            static long dwg = -1, dwm = -1;   // PP_TRAIN_DWFWD_GRID / _MINPX: workgroups of the persistent kernel, least pixels per thread
+            if (dwg < 0) { const char* e = getenv("PP_TRAIN_DWFWD_GRID"); dwg = e ? atol(e) : 1024; }
+            if (dwm < 0) { const char* e = getenv("PP_TRAIN_DWFWD_MINPX"); dwm = e ? atol(e) : 2; }     // (B=32 sweep, grid x pixels: 1024 x 4 0.275 ms, 1280 x 4 0.281, 1280 x 2 0.271, 1024 x 2 0.271, 1280 x 1 0.271, 2048 x 2 0.275; thread-per-output 0.331)
+            if (dwp && nthr >= dwm * dwg * 256) {      // at least dwm pixels per thread on a one-round grid
+                PP_LAUNCH("k_tr_dw_fwd", k_tr_dw_fwd_p, dim3((unsigned)dwg), dim3(256), 0, cx.stream, cur, L.p(pre + "/depthwise_kernel"),
+                          tb.D, B, l.in_h, l.in_w, l.out_h, l.out_w, l.cin, l.stride, cur_coef);
+            } else {
+                PP_LAUNCH("k_tr_dw_fwd", k_tr_dw_fwd, dim3(blocks_for(nthr)), dim3(256), 0, cx.stream, cur,
+                          L.p(pre + "/depthwise_kernel"), tb.D, (unsigned)nthr, l.in_h, l.in_w,
+                          make_div((unsigned)l.out_h), make_div((unsigned)l.out_w), make_div((unsigned)(l.cin / 4)), l.cin,
+                          l.stride, cur_coef);
+            }
             tr_gemm(cx, tb.D, l.cin, 1, L.p(pre + "/pointwise_kernel"), l.cout, 1, tb.Z, l.cout, (int)rows, l.cout, l.cin,
                     nullptr, 0, 1, cx.stat_part);
             // tb.A exists for the block-final layers only (the transposed convolution and the next block read it)
