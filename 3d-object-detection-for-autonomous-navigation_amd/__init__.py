@@ -8,7 +8,7 @@ or through the root-level alias module `pp_amd`.
 from . import config, anchors, weights, synth, frame_shard, anno, kitti_eval, ingest, target_assigner, optim  # noqa: F401  (host-side modules)
 from . import _lib  # noqa: F401  (ctypes binding of the C-ABI; loads lazily)
 from .voxel_generator import points_to_voxel  # noqa: F401
-from .engine import Engine  # noqa: F401
+from .engine import Engine, NumericError  # noqa: F401
 from .voxelnet import VoxelNet  # noqa: F401
 from .dataprep import prep_example, merge_batch  # noqa: F401
 from .trainer import Trainer  # noqa: F401

@@ -139,7 +139,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pix = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (pix < a.M) dst[(size_t)pix * a.ld_out] = fmaxf(acc[n][r] + bv, 0.f);
+                if (pix < a.M) dst[(size_t)pix * a.ld_out] = relu_keep_nan(acc[n][r] + bv);
             }
         }
     } else if (a.epi == 1) {
@@ -157,7 +157,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (p0 + row < a.M) dst[(size_t)(s_opix[row] + delta) * a.ld_out] = fmaxf(acc[n][r] + bv, 0.f);
+                if (p0 + row < a.M) dst[(size_t)(s_opix[row] + delta) * a.ld_out] = relu_keep_nan(acc[n][r] + bv);
             }
         }
     } else {
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(PXB * 4, (MODE == 0 && S == 2) ? 3 : 4) void k_gemm
         const float bvn = a.bias[cbase + n * 32 + r32];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            so[((r & 3) + 8 * (r >> 2) + 4 * h) * OSTR + n * 32 + r32] = fmaxf(acc[n][r] + bvn, 0.f);
+            so[((r & 3) + 8 * (r >> 2) + 4 * h) * OSTR + n * 32 + r32] = relu_keep_nan(acc[n][r] + bvn);
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1019,8 +1019,8 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
                 _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                     \
                     const float bvn = bias_r[n];                                                         \
                     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                      \
-                        float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);  \
-                        float x2 = fmaxf(acc[n][4 * g + 2] + bvn, 0.f), x3 = fmaxf(acc[n][4 * g + 3] + bvn, 0.f);  \
+                        float x0 = relu_keep_nan(acc[n][4 * g + 0] + bvn), x1 = relu_keep_nan(acc[n][4 * g + 1] + bvn);  \
+                        float x2 = relu_keep_nan(acc[n][4 * g + 2] + bvn), x3 = relu_keep_nan(acc[n][4 * g + 3] + bvn);  \
                         quad_transpose4(x0, x1, x2, x3, lane);                                           \
                         *reinterpret_cast<float4*>(dst + (8 * g) * ldo + n * 32) = make_float4(x0, x1, x2, x3);  \
                     }                                                                                    \
@@ -1029,8 +1029,8 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
                 _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                     \
                     const float bvn = bias_r[n];                                                         \
                     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                      \
-                        float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);  \
-                        float x2 = fmaxf(acc[n][4 * g + 2] + bvn, 0.f), x3 = fmaxf(acc[n][4 * g + 3] + bvn, 0.f);  \
+                        float x0 = relu_keep_nan(acc[n][4 * g + 0] + bvn), x1 = relu_keep_nan(acc[n][4 * g + 1] + bvn);  \
+                        float x2 = relu_keep_nan(acc[n][4 * g + 2] + bvn), x3 = relu_keep_nan(acc[n][4 * g + 3] + bvn);  \
                         quad_transpose4(x0, x1, x2, x3, lane);                                           \
                         if (pw + 8 * g + 4 * h + qi < a.M)                                               \
                             *reinterpret_cast<float4*>(dst + (8 * g) * ldo + n * 32) = make_float4(x0, x1, x2, x3);  \
@@ -1288,8 +1288,8 @@ __global__ __launch_bounds__(512, 1) void k_sep_p(GemmArgs a, int ntiles) {
             _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                         \
                 const float bvn = bias_r[n];                                                             \
                 _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                          \
-                    float x0 = fmaxf(acc[n][4 * g + 0] + bvn, 0.f), x1 = fmaxf(acc[n][4 * g + 1] + bvn, 0.f);  \
-                    float x2 = fmaxf(acc[n][4 * g + 2] + bvn, 0.f), x3 = fmaxf(acc[n][4 * g + 3] + bvn, 0.f);  \
+                    float x0 = relu_keep_nan(acc[n][4 * g + 0] + bvn), x1 = relu_keep_nan(acc[n][4 * g + 1] + bvn);  \
+                    float x2 = relu_keep_nan(acc[n][4 * g + 2] + bvn), x3 = relu_keep_nan(acc[n][4 * g + 3] + bvn);  \
                     quad_transpose4(x0, x1, x2, x3, lane);                                               \
                     if (pw + 8 * g + 4 * h + qi < a.M)                                                   \
                         *reinterpret_cast<float4*>(dst + (8 * g) * ldo + n * 32) = make_float4(x0, x1, x2, x3);  \
@@ -1516,8 +1516,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_sep_k4(GemmArgs a)
                 const float4 u = *reinterpret_cast<const float4*>(smem + (((w * NTILES + wave) * 4 + g) * 64 + lane) * 4);
                 t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             }
-            float x0 = fmaxf(t.x + bias_w, 0.f), x1 = fmaxf(t.y + bias_w, 0.f);
-            float x2 = fmaxf(t.z + bias_w, 0.f), x3 = fmaxf(t.w + bias_w, 0.f);
+            float x0 = relu_keep_nan(t.x + bias_w), x1 = relu_keep_nan(t.y + bias_w);
+            float x2 = relu_keep_nan(t.z + bias_w), x3 = relu_keep_nan(t.w + bias_w);
             quad_transpose4(x0, x1, x2, x3, lane);
             if (pw + 8 * g + 4 * h + qi < a.M)
                 *reinterpret_cast<float4*>(dst + (size_t)(8 * g) * a.ld_out) = make_float4(x0, x1, x2, x3);
@@ -1590,7 +1590,7 @@ __device__ __forceinline__ void deconv_tile_epilogue(const GemmArgs& a, f32x16 (
     for (int n = 0; n < NTILES; ++n) {
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[n][r], 0.f);   // the folded bias is the accumulator's initial value
+        for (int r = 0; r < 16; ++r) v[r] = relu_keep_nan(acc[n][r]);   // the folded bias is the accumulator's initial value
         if (heads) {
             // the activated values are already a B operand (k = channel, column = pixel) up to a fixed
             // permutation of k, which the head kernels carry as well (pp_api.hip: head_k_permutation)
@@ -2045,7 +2045,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_r(GemmArgs a, int nunits, int
             if (c == NCH - 1) {          // n-tile nt complete: ReLU [+ concat slice] [+ its share of the head GEMM]
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r], 0.f);
+                for (int r = 0; r < 16; ++r) v[r] = relu_keep_nan(acc[r]);
                 if (heads && !R_ABL(2)) {
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
@@ -2254,7 +2254,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_k4(GemmArgs a) {
                 }
             }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r] + s_bias[wave * 32 + DCH(r, h)], 0.f);
+        for (int r = 0; r < 16; ++r) v[r] = relu_keep_nan(v[r] + s_bias[wave * 32 + DCH(r, h)]);
         if (a.out != nullptr && ok) {
             float* dst = a.out + orow * a.ld_out + a.co_off + cbase + 4 * h + wave * 32;
 #pragma unroll

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     __shared__ unsigned long long s_mask[KMAX][2];
     __shared__ int s_keep[KMAX];
     __shared__ int s_nkeep;
+    __shared__ int s_bad;      // a non-finite class logit anywhere in the frame, or a non-finite value in a selected row
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
 #ifdef PP_POST_STAMPS   // diagnostic build: phase times of frame 0 (100 MHz ticks), printed by thread 0
@@ -74,12 +75,17 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     // candidate scan source: the compact class-logit plane the last deconv left (napl*ncls floats per pixel,
     // consecutive anchors = consecutive words) or, without it, the cls columns of the 128-byte head rows
     const float* cplane = (p.cls != nullptr) ? p.cls + (size_t)b * A * ncls : nullptr;
+    // Non-finite head outputs (the split-precision GEMMs carry an operand as two float16 pieces: an activation beyond
+    // +-65504 becomes inf - inf = NaN in the product; the ReLUs of the backbone keep a NaN, relu_keep_nan) must not
+    // turn into boxes: every class logit of the frame passes through here, masked or not, and the frame is flagged.
+    bool bad = false;
     auto cls_of = [&](long long a) -> float {
         const long long px = a / napl;
         const float* q = (cplane != nullptr) ? cplane + a * ncls
                                              : head + px * PP_HEAD_COLS + nb + (int)(a - px * napl) * ncls;
         float m = q[0];
-        for (int k = 1; k < ncls; ++k) m = fmaxf(m, q[k]);
+        bad |= !pp_finite(m);
+        for (int k = 1; k < ncls; ++k) { bad |= !pp_finite(q[k]); m = fmaxf(m, q[k]); }
         return m;
     };
     const float thr = p.score_thr;
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
     };
 
     // ---- candidates -> LDS once (the head map is read a single time; the select passes run on LDS) ----
-    if (tid == 0) { s_prefix = 0ull; s_need = KTOP; s_shift = 56; s_done = 0; s_cnt = 0; s_ncand = 0; }
+    if (tid == 0) { s_prefix = 0ull; s_need = KTOP; s_shift = 56; s_done = 0; s_cnt = 0; s_ncand = 0; s_bad = 0; }
     __syncthreads();
     // (16 anchors per thread at a time; the logit loads do not wait for the mask bytes -- nearly every anchor
     // is a candidate -- so a frame of up to 16 384 anchors costs one memory round trip)
@@ -121,6 +127,7 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
             if (pos < CCAP) s_ckey[pos] = comp_key(lgs[k], (unsigned)(a0 + (long long)k * PT));
         }
     }
+    if (bad) s_bad = 1;
     __syncthreads();
     P_STAMP()   // candidates gathered
     const int ncand = s_ncand;
@@ -258,6 +265,12 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         const float* d = hrow + nb + nc + ar * 2;
         s_dir[tid] = (p.use_dir && d[1] > d[0]) ? 1 : 0;  // np.argmax: first maximum
         s_anchor[tid] = (int)a;
+        {
+            bool rb = !pp_finite(d[0]) || !pp_finite(d[1]);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) rb |= !pp_finite(e[q]);
+            if (rb) s_bad = 1;      // (the class logits were checked by the scan)
+        }
         // corners (-,-),(-,+),(+,+),(+,-) * dims, rotate by [[c,-s],[s,c]], + centre; min/max
         const float sn = sinf(rg), cs = cosf(rg);
         const float hx = __fmul_rn(wg, 0.5f), hy = __fmul_rn(lg, 0.5f);
@@ -344,8 +357,9 @@ __global__ __launch_bounds__(PT) void k_postprocess(PostParams p) {
         if (lane + 64 < nk) s_keep[lane + 64] = k1;
         if (lane == 0) {
             s_nkeep = nk;
-            p.n_dets[b] = nk;
-            if (p.n_dets_host != nullptr) p.n_dets_host[b] = nk;
+            const int flagged = nk | (s_bad ? PP_NDETS_NONFINITE : 0);   // pp_get_detections / pp_predict: PP_ERR_NUMERIC
+            p.n_dets[b] = flagged;
+            if (p.n_dets_host != nullptr) p.n_dets_host[b] = flagged;
         }
     }
     __syncthreads();

@@ -142,6 +142,7 @@ struct pp_engine {
     TrainState* train = nullptr;
     bool mask_in_pfn = false;      // the last run_pfn also computed the anchor mask (few frames)
     int f32_fallback_layers = 0;   // layers whose folded weights do not fit float16 pieces (pp_finalize_weights)
+    bool force_f32 = false;        // pp_set_gemm_precision(PP_PREC_F32): no layer gets split weights
 
     int prof = 0;
     // pp_detect_async as one hipGraph launch (captured on first use per (batch, max points per frame))
@@ -917,7 +918,7 @@ int pp_finalize_weights(pp_handle e) {
             int st = upload(e, &L.d_dw, *dw); if (st) return st;
             st = upload(e, &L.d_wt, wt); if (st) return st;
             L.d_wt16 = nullptr;
-            if (L.cin % 16 == 0 && f16_pair_range_ok(wt)) { st = upload(e, &L.d_wt16, split_weights_bf16x3(wt, L.n_total, L.cin)); if (st) return st; }
+            if (!e->force_f32 && L.cin % 16 == 0 && f16_pair_range_ok(wt)) { st = upload(e, &L.d_wt16, split_weights_bf16x3(wt, L.n_total, L.cin)); if (st) return st; }
             else ++e->f32_fallback_layers;
             st = upload(e, &L.d_bias, sh); if (st) return st;
             ++li;
@@ -933,7 +934,7 @@ int pp_finalize_weights(pp_handle e) {
             int st = upload(e, &L.d_wt, wt); if (st) return st;
             L.d_wt16 = nullptr;
             L.d_head_wt16 = nullptr;
-            if (L.cin % 16 == 0 && f16_pair_range_ok(wt)) { st = upload(e, &L.d_wt16, split_weights_bf16x3(wt, L.n_total, L.cin)); if (st) return st; }
+            if (!e->force_f32 && L.cin % 16 == 0 && f16_pair_range_ok(wt)) { st = upload(e, &L.d_wt16, split_weights_bf16x3(wt, L.n_total, L.cin)); if (st) return st; }
             else ++e->f32_fallback_layers;
             st = upload(e, &L.d_bias, sh); if (st) return st;
             if (L.head_mode != 0) {   // this branch's [PP_HEAD_COLS][cout] slice of the head matrix
@@ -941,7 +942,7 @@ int pp_finalize_weights(pp_handle e) {
                 for (int o = 0; o < PP_HEAD_COLS; ++o)
                     for (int c = 0; c < L.cout; ++c) hw[(size_t)o * L.cout + c] = headw[(size_t)o * e->CC + L.co_off + c];
                 st = upload(e, &L.d_head_wt, hw); if (st) return st;
-                if (L.cout % 32 == 0 && f16_pair_range_ok(hw)) {
+                if (!e->force_f32 && L.cout % 32 == 0 && f16_pair_range_ok(hw)) {
                     // k_deconv_u feeds the head GEMM from its accumulator registers: slot (h, j) of 16-channel group
                     // (n, g) holds channel n*32 + (j&3) + 8*(2g + (j>>2)) + 4h (the 32x32 MFMA result layout); the
                     // head kernels get the same order of k
@@ -1280,6 +1281,35 @@ int pp_sync(pp_handle e) {
     return PP_OK;
 }
 
+// k_postprocess flags a frame whose head maps hold a non-finite value in bit PP_NDETS_NONFINITE of its count
+static int check_numeric(pp_engine* e, const int* n_dets, int B, const char* who) {
+    int bad = 0, first = -1;
+    for (int b = 0; b < B; ++b)
+        if (n_dets[b] & PP_NDETS_NONFINITE) { if (first < 0) first = b; ++bad; }
+    if (!bad) return PP_OK;
+    return fail(e, PP_ERR_NUMERIC, "%s: non-finite head outputs in %d of %d frames (first: frame %d); %s", who, bad, B, first,
+                e->force_f32 ? "the network overflows float32 on these inputs"
+                             : "an activation left the range of the float16 operand pieces (|x| < 65504): "
+                               "pp_set_gemm_precision(h, PP_PREC_F32) and run the frames again");
+}
+
+int pp_set_gemm_precision(pp_handle e, int32_t precision) {
+    if (!e) return PP_ERR_ARG;
+    if (precision != PP_PREC_SPLIT_F16 && precision != PP_PREC_F32) return fail(e, PP_ERR_ARG, "pp_set_gemm_precision: unknown precision %d", precision);
+    const bool f32 = precision == PP_PREC_F32;
+    if (f32 == e->force_f32) return PP_OK;
+    if (e->train_pending) return fail(e, PP_ERR_STATE, "pp_set_gemm_precision: a training step is in flight");
+    e->force_f32 = f32;
+    if (!e->weights_ready) return PP_OK;
+    return pp_finalize_weights(e);       // waits for the stream, drops the graphs, rebuilds the device weights
+}
+
+int pp_get_gemm_precision(pp_handle e, int32_t* precision) {
+    if (!e || !precision) return PP_ERR_ARG;
+    *precision = e->force_f32 ? PP_PREC_F32 : PP_PREC_SPLIT_F16;
+    return PP_OK;
+}
+
 int pp_get_detections(pp_handle e, pp_detection* dets, int32_t* n_dets) {
     if (!e) return PP_ERR_ARG;
     if (!dets || !n_dets) return fail(e, PP_ERR_ARG, "pp_get_detections: NULL argument");
@@ -1289,6 +1319,7 @@ int pp_get_detections(pp_handle e, pp_detection* dets, int32_t* n_dets) {
     HIPCHK(e, hipStreamSynchronize(e->stream));   // immediate after pp_sync; never hands out a half-written buffer
     // the kept detections of every frame, zeros behind them (the kernel writes only what it keeps)
     const size_t pm = (size_t)e->cfg.nms_post_max_size;
+    if (int st = check_numeric(e, e->h_ndets, B, "pp_get_detections")) return st;
     for (int b = 0; b < B; ++b) {
         size_t n = (size_t)std::max(0, std::min(e->h_ndets[b], (int)pm));
         memcpy(dets + (size_t)b * pm, e->h_dets + (size_t)b * pm, n * sizeof(pp_detection));
@@ -1419,6 +1450,12 @@ int pp_predict(pp_handle e, const float* box_preds, const float* cls_preds, cons
     HIPCHK(e, hipMemcpyAsync(n_dets, e->d_ndets, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     stage_call_done(e);
+    // non-finite predictions: the reference's predict() would hand NaN boxes on (np.argpartition over NaN scores);
+    // this one says so instead (documented deviation)
+    if ((st = check_numeric(e, n_dets, batch, "pp_predict"))) {
+        for (int b = 0; b < batch; ++b) n_dets[b] = 0;
+        return st;
+    }
     return PP_OK;
 }
 

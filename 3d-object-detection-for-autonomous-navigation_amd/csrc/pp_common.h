@@ -50,6 +50,12 @@ bool pp_prof_events(const char* name, hipEvent_t* start, hipEvent_t* stop);   //
 // inclusive prefix sum over the 64 lanes of a wave with DPP adds (row shifts inside the rows of 16, then the two row
 // broadcasts): six short VALU operations instead of six ds_bpermute round trips (__shfl_up) -- the scans of the
 // single-workgroup stages are dependent chains: their latency is what they cost
+// Requirements: all 64 lanes of the wave active at the call (the row shifts read inactive lanes as 0 only through
+// bound_ctrl; every caller scans whole waves), and a wave64 GFX9 target: row_bcast:15 / :31 do not exist elsewhere.
+// This library is written for gfx950 only -- any other --offload-arch stops here instead of mis-scanning.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "pp_common.h: the DPP wave scans (row_bcast) and the MFMA kernels of this library target gfx950 (MI355X) only"
+#endif
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
     v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
@@ -60,6 +66,15 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     return v;
 }
 
+
+// ----- numeric guard of the split-precision GEMM path ----------------------------------
+// v_max_f32 (fmaxf) returns the OTHER operand when one is a NaN: a ReLU written with it would turn the NaN an
+// out-of-range activation produces (two float16 pieces: |x| >= 65520 -> inf - inf) into a clean 0 and the frame into
+// silently wrong boxes.  The backbone's ReLUs keep a NaN, so it reaches the head maps, where the post-process sees it
+// (bit PP_NDETS_NONFINITE of a frame's detection count -> PP_ERR_NUMERIC).
+__device__ __forceinline__ float relu_keep_nan(float x) { return (x < 0.f) ? 0.f : x; }
+__device__ __forceinline__ bool pp_finite(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
+#define PP_NDETS_NONFINITE (1 << 30)
 
 // ----- voxel grid geometry (float64, as the reference's index math) -----
 struct VoxGeom {

@@ -15,7 +15,15 @@ from .anchors import build_anchor_cells, build_anchors
 from .config import Derived
 from .weights import check_weights
 
-_STATUS = {1: "PP_ERR_ARG", 2: "PP_ERR_STATE", 3: "PP_ERR_HIP", 4: "PP_ERR_SHAPE", 5: "PP_ERR_UNSUPPORTED"}
+_STATUS = {1: "PP_ERR_ARG", 2: "PP_ERR_STATE", 3: "PP_ERR_HIP", 4: "PP_ERR_SHAPE", 5: "PP_ERR_UNSUPPORTED",
+           6: "PP_ERR_NUMERIC"}
+PP_ERR_NUMERIC = 6
+_PRECISIONS = {"split_f16": 0, "f32": 1}
+
+
+class NumericError(RuntimeError):
+    """PP_ERR_NUMERIC: a frame's head maps hold a non-finite value (an activation beyond the float16 operand pieces'
+    range in the default arithmetic, or a network that overflows float32).  No detections were handed out."""
 
 DET_DTYPE = np.dtype([
     ("box3d_camera", np.float64, (7,)), ("box3d_lidar", np.float32, (7,)), ("score", np.float32),
@@ -152,7 +160,21 @@ class Engine:
     def _check(self, st, what):
         if st != 0:
             msg = self._lib.pp_last_error(self._h)
-            raise RuntimeError(f"{what} failed ({_STATUS.get(st, st)}): {msg.decode() if msg else ''}")
+            cls = NumericError if st == PP_ERR_NUMERIC else RuntimeError
+            raise cls(f"{what} failed ({_STATUS.get(st, st)}): {msg.decode() if msg else ''}")
+
+    # ---- GEMM arithmetic (pp_set_gemm_precision) ----
+    def set_gemm_precision(self, precision):
+        """'split_f16' (default: fp32 results from two float16 pieces per operand on the 16-bit matrix pipe) or 'f32'
+        (the float32 matrix instruction everywhere: float32's range, about a sixth of the matrix rate)."""
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self._check(self._lib.pp_set_gemm_precision(self._h, _PRECISIONS[precision]), "pp_set_gemm_precision")
+
+    def gemm_precision(self):
+        v = ctypes.c_int32(0)
+        self._check(self._lib.pp_get_gemm_precision(self._h, ctypes.byref(v)), "pp_get_gemm_precision")
+        return {v_: k for k, v_ in _PRECISIONS.items()}[v.value]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -319,8 +341,20 @@ class Engine:
         self._check(self._lib.pp_get_detections(self._h, _ptr(dets), _ptr(n)), "pp_get_detections")
         return dets, n
 
-    def detect(self, frames, rect=None, trv2c=None):
+    def detect(self, frames, rect=None, trv2c=None, on_numeric="f32"):
+        """upload + detect_async + sync + detections.  on_numeric: what to do when the default arithmetic reports
+        activations outside the float16 pieces' range (NumericError) -- "f32": switch this engine to the float32
+        matrix instruction (it stays there: `gemm_precision()`), run the still-resident frames again and return those
+        results; "raise": propagate.  A network that overflows float32 itself always raises."""
         self.upload(frames, rect, trv2c)
+        self.detect_async()
+        self.sync()
+        try:
+            return self.detections()
+        except NumericError:
+            if on_numeric != "f32" or self.gemm_precision() == "f32":
+                raise
+        self.set_gemm_precision("f32")
         self.detect_async()
         self.sync()
         return self.detections()

@@ -71,13 +71,28 @@ def gpu_numa_node(pci_bus_id, sysfs="/sys"):
     return node if node >= 0 else None
 
 
-def pin_to_gpu_numa_node(pci_bus_id, sysfs="/sys", apply=True):
-    """Restricts this process (and the threads it starts later) to the CPUs of the GPU's NUMA node, BEFORE the rank
-    allocates its page-locked staging pool: first-touch then places those pages on the node the GPU's host link
-    hangs off, and the feeding thread stays next to them.  Only CPUs the process may already use are kept (cgroup /
-    taskset limits are respected).  Returns a report dict; never raises -- a box without the sysfs files, or whose
-    node has none of our CPUs, is left as it is."""
+_saved_affinity = None      # {tid: mask} of the last pin, for restore_affinity()
+
+
+def _all_task_ids():
+    """Thread ids of this process (runtime / communicator threads started before the pin included)."""
     import os
+    try:
+        return sorted(int(t) for t in os.listdir("/proc/self/task"))
+    except OSError:
+        return [0]
+
+
+def pin_to_gpu_numa_node(pci_bus_id, sysfs="/sys", apply=True):
+    """Restricts EVERY thread of this process -- the ones the HIP runtime or the communicator have already started as
+    well as the ones started later, which inherit the caller's mask -- to the CPUs of the GPU's NUMA node, BEFORE the
+    rank allocates its page-locked staging pool: first-touch then places those pages on the node the GPU's host link
+    hangs off, and the feeding thread stays next to them.  Only CPUs the process may already use are kept (cgroup /
+    taskset limits are respected).  `restore_affinity()` undoes it (host-side legs that want the whole machine, e.g.
+    a CPU baseline).  Returns a report dict; never raises -- a box without the sysfs files, or whose node has none of
+    our CPUs, is left as it is."""
+    import os
+    global _saved_affinity
     rep = {"pci_bus_id": pci_bus_id, "numa_node": None, "pinned": False}
     try:
         node = gpu_numa_node(pci_bus_id, sysfs)
@@ -93,12 +108,40 @@ def pin_to_gpu_numa_node(pci_bus_id, sysfs="/sys", apply=True):
             rep["reason"] = "none of the node's CPUs is in this process's affinity mask"
             return rep
         if apply and keep != allowed:
-            os.sched_setaffinity(0, keep)
+            saved, threads = {}, 0
+            for tid in _all_task_ids():
+                try:
+                    saved[tid] = os.sched_getaffinity(tid)
+                    os.sched_setaffinity(tid, keep & saved[tid] or keep)
+                    threads += 1
+                except OSError:          # the thread ended between the listing and the call
+                    saved.pop(tid, None)
+            _saved_affinity = saved
+            rep["threads"] = threads
         rep["pinned"] = True
         rep["cpus"] = len(keep)
     except Exception as ex:   # noqa: BLE001 -- placement is an optimisation, never a failure
         rep["reason"] = repr(ex)
     return rep
+
+
+def restore_affinity():
+    """Gives every thread pinned by the last pin_to_gpu_numa_node() its previous CPU mask back (threads started since
+    then get the calling thread's restored mask).  Returns the number of threads restored."""
+    import os
+    global _saved_affinity
+    saved, _saved_affinity = _saved_affinity, None
+    if not saved:
+        return 0
+    me = saved.get(os.getpid()) or next(iter(saved.values()))
+    n = 0
+    for tid in _all_task_ids():
+        try:
+            os.sched_setaffinity(tid, saved.get(tid, me))
+            n += 1
+        except OSError:
+            pass
+    return n
 
 
 def device_pci_bus_id(local_rank):

@@ -37,6 +37,8 @@ class Trainer:
         self.engine = Engine(config, max_batch=max_batch, max_points_per_frame=max_points_per_frame, device=device)
         self._prefetched = None      # the TrainBatch whose points are already on their way (forward_backward(prefetch=))
         self._ext_stream = None      # torch.cuda.ExternalStream over the engine's stream (_engine_stream)
+        self.time_allreduce = False  # True: every step's gradient all-reduce is bracketed by an event pair (allreduce_ms)
+        self._allreduce_events = []
         d = self.engine.d
         self.layout, n_params, n_state = self.engine.train_layout()
         self.device = torch.device("cuda", device)
@@ -148,8 +150,20 @@ class Trainer:
 
     def _enqueue_update(self, dist):
         with self.torch.cuda.stream(self._engine_stream()):
+            if self.time_allreduce:      # an event pair around the exchange alone, on the stream it runs on
+                ev = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             optim.allreduce_gradients(self.grads, dist)        # one collective per step over the flat buffer
+            if self.time_allreduce:
+                ev[1].record()
+                self._allreduce_events.append(ev)
             self.optimizer.apply_gradients(self.grads)
+
+    def allreduce_ms(self):
+        """Device time (ms) of each gradient exchange since `time_allreduce` was set (call after the steps were waited
+        for); the list is emptied."""
+        evs, self._allreduce_events = self._allreduce_events, []
+        return [a.elapsed_time(b) for a, b in evs]
 
     def apply_gradients(self, dist=None):
         """optimizer.apply_gradients (train.py:301) after the data-parallel mean of the flat gradient buffer.  The
@@ -162,8 +176,21 @@ class Trainer:
         """One optimizer step: forward + loss + backward, gradient exchange, AdamW -- enqueued back to back on the engine's
         stream, ONE host wait at the end."""
         self._launch(frames, labels, reg_targets, prefetch)
-        self._enqueue_update(dist)
+        try:
+            self._enqueue_update(dist)
+        except BaseException:
+            # the step is in flight: wait for it (its own error is secondary) so the engine is not left "pending",
+            # and forget the prefetch -- the next call uploads its batch itself
+            self._abandon_step()
+            raise
         return self.engine.train_step_wait()
+
+    def _abandon_step(self):
+        self._prefetched = None
+        try:
+            self.engine.train_step_wait()
+        except Exception:      # noqa: BLE001 -- the caller's exception is the one to report
+            pass
 
     def close(self):
         self.engine.close()

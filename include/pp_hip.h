@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 2
+#define PP_ABI_VERSION 3
 
 enum pp_status {
     PP_OK = 0,
@@ -35,7 +35,17 @@ enum pp_status {
     PP_ERR_STATE = 2,  /* call order: weights or anchors not set */
     PP_ERR_HIP = 3,    /* a HIP runtime call failed (see pp_last_error) */
     PP_ERR_SHAPE = 4,  /* tensor shape does not match the configuration */
-    PP_ERR_UNSUPPORTED = 5
+    PP_ERR_UNSUPPORTED = 5,
+    PP_ERR_NUMERIC = 6 /* non-finite head outputs: pp_get_detections / pp_detect / pp_predict never hand out NaN boxes */
+};
+
+/* GEMM arithmetic of the backbone (pp_set_gemm_precision) */
+enum pp_gemm_precision {
+    PP_PREC_SPLIT_F16 = 0, /* default: fp32 results on the 16-bit matrix pipe, every operand as two float16 pieces.
+                            * Needs |BN-folded weight| < 32768 (checked per layer at pp_finalize_weights: a layer that
+                            * fails runs in PP_PREC_F32 by itself) and |activation| < 65504 (checked on the device:
+                            * a frame whose activations leave the range ends in PP_ERR_NUMERIC) */
+    PP_PREC_F32 = 1        /* every layer on the float32 matrix instruction (v_mfma_f32_32x32x2_f32): float32's range */
 };
 
 typedef struct pp_engine* pp_handle;
@@ -192,8 +202,18 @@ int pp_detect_async(pp_handle h);
 /* Waits for the engine's stream. */
 int pp_sync(pp_handle h);
 /* Copies the results of the last pp_detect_async (waits for the engine's stream first; immediate after
- * pp_sync).  dets [batch*nms_post_max_size], n_dets [batch].  PP_ERR_STATE when there are none. */
+ * pp_sync).  dets [batch*nms_post_max_size], n_dets [batch].  PP_ERR_STATE when there are none.
+ * PP_ERR_NUMERIC when a frame's head maps hold a non-finite value (pp_last_error names the frame): with
+ * PP_PREC_SPLIT_F16 that is an activation beyond the float16 pieces' range -- the frames are still resident, so
+ * pp_set_gemm_precision(h, PP_PREC_F32) + pp_detect_async + pp_get_detections re-runs them in float32; in PP_PREC_F32
+ * the network itself overflowed (the reference, model/voxelnet.py:1060-1390, would return NaN boxes).  Nothing is
+ * written to dets / n_dets in that case. */
 int pp_get_detections(pp_handle h, pp_detection* dets, int32_t* n_dets);
+/* Selects the backbone's GEMM arithmetic (enum pp_gemm_precision) for this handle; re-derives the device weights
+ * (pp_finalize_weights' work) when they are loaded.  Waits for the handle's stream.  The default comes from the
+ * environment (PP_GEMM_PREC=f32) or is PP_PREC_SPLIT_F16. */
+int pp_set_gemm_precision(pp_handle h, int32_t precision);
+int pp_get_gemm_precision(pp_handle h, int32_t* precision);
 /* Convenience: upload + calib + detect + sync + get (the evaluate loop body,
  * train.py:689-786 minus annotation formatting). */
 int pp_detect(pp_handle h, const float* points, const int32_t* frame_offsets, int32_t batch,

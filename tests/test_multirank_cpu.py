@@ -82,7 +82,27 @@ def test_numa_pinning_from_sysfs(pp, tmp_path):
     try:
         rep = pp.frame_shard.pin_to_gpu_numa_node("0000:0c:00.0", sysfs=str(tmp_path), apply=True)
         assert rep["pinned"] and sorted(os.sched_getaffinity(0)) == half
+        # a pin covers the threads that already exist (runtime / communicator threads), and can be undone
+        assert pp.frame_shard.restore_affinity() >= 1 and sorted(os.sched_getaffinity(0)) == allowed
+        import threading
+        stop, seen = threading.Event(), {}
+
+        def other():
+            seen["tid"] = threading.get_native_id()
+            stop.wait(30)
+        t = threading.Thread(target=other)
+        t.start()
+        while "tid" not in seen:
+            pass
+        rep = pp.frame_shard.pin_to_gpu_numa_node("0000:0c:00.0", sysfs=str(tmp_path), apply=True)
+        if len(half) < len(allowed):
+            assert rep["threads"] >= 2 and sorted(os.sched_getaffinity(seen["tid"])) == half
+            pp.frame_shard.restore_affinity()
+            assert sorted(os.sched_getaffinity(seen["tid"])) == allowed
+        stop.set()
+        t.join()
     finally:
+        pp.frame_shard.restore_affinity()
         os.sched_setaffinity(0, allowed)
     (dev / "numa_node").write_text("-1\n")
     rep = pp.frame_shard.pin_to_gpu_numa_node("0000:0c:00.0", sysfs=str(tmp_path))
@@ -90,3 +110,41 @@ def test_numa_pinning_from_sysfs(pp, tmp_path):
     rep = pp.frame_shard.pin_to_gpu_numa_node("0000:ff:00.0", sysfs=str(tmp_path))     # unknown device
     assert not rep["pinned"]
     assert pp.frame_shard._parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+
+
+def _numa_worker(rank, sysfs, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import pp_amd as pp
+    bdf = ["0000:0c:00.0", "0000:8c:00.0"][rank]           # what device_pci_bus_id(local_rank) returns on the node
+    rep = pp.frame_shard.pin_to_gpu_numa_node(bdf, sysfs=sysfs)
+    q.put((rank, rep, sorted(os.sched_getaffinity(0))))
+
+
+def test_two_ranks_on_different_numa_nodes_pin_differently(tmp_path):
+    """bench.py --gpus N: every rank pins itself to ITS GPU's node.  Two GPUs on two nodes (fake sysfs, the CPUs this
+    container has split in two): the ranks' reports (`config.numa`) and masks differ."""
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip("one CPU")
+    halves = [allowed[:len(allowed) // 2], allowed[len(allowed) // 2:]]
+    for node, bdf in enumerate(["0000:0c:00.0", "0000:8c:00.0"]):
+        dev = tmp_path / "bus" / "pci" / "devices" / bdf
+        dev.mkdir(parents=True)
+        (dev / "numa_node").write_text(f"{node}\n")
+        nd = tmp_path / "devices" / "system" / "node" / f"node{node}"
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(",".join(str(c) for c in halves[node]) + "\n")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_numa_worker, args=(r, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, rep0, m0), (_, rep1, m1) = res
+    assert rep0["pinned"] and rep1["pinned"]
+    assert rep0["numa_node"] == 0 and rep1["numa_node"] == 1
+    assert m0 == halves[0] and m1 == halves[1] and not set(m0) & set(m1)
