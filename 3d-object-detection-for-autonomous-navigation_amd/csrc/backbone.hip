@@ -26,6 +26,7 @@
 // (which share halo rows) land on the same XCD / L2.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "pp_common.h"
 
@@ -68,6 +69,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void buf_store16(float4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffffe, 0x00020000);
@@ -121,6 +126,12 @@ struct GemmArgs {
     // of the head map for its candidate scan (8 bytes per pixel instead of a 128-byte row); NULL: not written
     float* cls_plane;
     int cls_col0, cls_ncol;
+    // training-mode forward of a separable layer (k_sep_u<..., TR = 1>, launch_sep_train):
+    const float4* tr_coef;   // [cin] (sc, sh, ., .): the input map is the PRE-BatchNorm map of the layer before and the
+                             // activation relu(z * sc + sh) is evaluated on the way in; NULL: the input is a tensor
+    float* tr_D;             // depthwise output [M][cin], kept for the weight-gradient product (or NULL)
+    float* tr_stat;          // BatchNorm statistics partials [gridDim.x][2][n_total]: column sums / sums of squares
+                             // of the output rows each workgroup produced
 };
 
 // D[row][col] of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -770,8 +781,16 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float inv_d, int& q, i
 // PREC 0: float32 MFMA (v_mfma_f32_32x32x2_f32); PREC 1: split-precision bf16 MFMA (see split_bf16x3).
 // OCC 1: the input is the sparse canvas (only cells that hold a pillar were written): every window position
 // looks its cell up in the cell -> pillar map at tile start and reads the zero header when it is empty.
-template <int NT, int S, int WPS, int PREC, int OCC = 0>
+// TR 1: the TRAINING-mode forward of the layer (train.hip, model/voxelnet.py:576-660 with training=True): the input is
+// the pre-BatchNorm map of the layer before, activated on the way in with that layer's batch-statistics coefficients
+// (two more "tap" vectors per channel group: sc, sh; the padding comes from a NaN header -- v_max_f32(NaN, 0) = 0 -- so
+// no window element is ever masked or selected); the depthwise output is also stored (the weight-gradient product's
+// operand); the epilogue writes the raw product (this layer's pre-BatchNorm map) and the column sums / sums of squares
+// of each wave's 32 rows for the batch statistics.  PREC 1 only.
+template <int NT, int S, int WPS, int PREC, int OCC = 0, int TR = 0>
 __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
+    static_assert(TR == 0 || (PREC == 1 && OCC == 0), "training forward: split-precision, dense input");
+    constexpr int NTAP = TR ? 11 : 9;                // tap vectors per channel group in LDS (TR: + sc, sh)
     constexpr int KCH = 16, LSTR = KCH + 4, G = 4;
     constexpr int WW = S + 3;                        // input window width of 2 adjacent output pixels
     constexpr int NLD = 3 * WW;
@@ -782,7 +801,8 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     constexpr int NB4 = (PREC == 0) ? (NT * G + 255) / 256 : (NT * 2 * PP_NPIECE + 255) / 256;   // 16-byte weight items per thread per chunk
     constexpr int NTILES = NT / 32;
     constexpr int KQ = KCH / 8;
-    __shared__ __attribute__((aligned(16))) float smem[8 * SAW + 2 * SB + 9 * 256];
+    // (TR: + the workgroup's running column sums / sums of squares, one [2][NT] row per wave)
+    __shared__ __attribute__((aligned(16))) float smem[8 * SAW + 2 * SB + NTAP * 256 + (TR ? 8 * NT : 0)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.dbg & 128) return;   // tuning aid: launch + dispatch cost only
 #ifdef PP_KERNEL_STAMPS   // diagnostic build: wall-clock phase stamps of every workgroup (wave 0)
@@ -800,6 +820,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     float* const sAw = smem + wave * 2 * SAW;
     float* const sB = smem + 8 * SAW;
     float* const sDW = smem + 8 * SAW + 2 * SB;
+    [[maybe_unused]] float* const sST = smem + 8 * SAW + 2 * SB + NTAP * 256;
 
     // ---- this workgroup's tiles: XCD x (= blockIdx.x & 7, the dispatch order) owns the contiguous tile
     // range [x * ntiles / 8, (x + 1) * ntiles / 8); its workgroups walk that range together, so the halo
@@ -807,9 +828,13 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     const int xcd = blockIdx.x & 7, gl = blockIdx.x >> 3, GL = gridDim.x >> 3;
     const int tbase = (int)(((long long)xcd * ntiles) >> 3), tend = (int)(((long long)(xcd + 1) * ntiles) >> 3);
     const int first = tbase + gl;
-    if (first >= tend) return;                         // uniform for the workgroup
-    const int ntl = (tend - first + GL - 1) / GL;      // tiles of this workgroup
     const int n0 = blockIdx.y * NT;
+    if (first >= tend) {                               // uniform for the workgroup
+        if (TR && tid < 2 * NT)                        // its (all-zero) row of the statistics partials
+            a.tr_stat[((size_t)blockIdx.x * 2 + tid / NT) * a.n_total + n0 + tid % NT] = 0.f;
+        return;
+    }
+    const int ntl = (tend - first + GL - 1) / GL;      // tiles of this workgroup
     const int cin = a.cin;
     const int nchunks = cin / KCH;
 #ifdef PP_KERNEL_STAMPS
@@ -827,11 +852,19 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)a.px_w;
     const int rs4 = a.in_w * cin * 4, cin4 = cin * 4;
     unsigned aoff[NLD];
+    // TR: byte offset of this lane's first output pixel's depthwise row in tr_D (+ its 4 channels); beyond the
+    // buffer's range when the pixel pair does not exist -- the buffer store is then dropped by the hardware
+    [[maybe_unused]] unsigned doff = 0x80000000u;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(TR ? (const void*)a.tr_D : (const void*)a.in);
+    [[maybe_unused]] const bool d_out = TR && a.tr_D != nullptr && blockIdx.y == 0;
+    // the input is a pre-BatchNorm map (NaN header) to be activated on the way in, or a tensor (zero header) read as it is
+    [[maybe_unused]] const bool tr_act = TR && a.tr_coef != nullptr;
     // byte offsets of the 3 x WW window of this lane's pixel pair in tile `tile` (out-of-map -> zero header)
 #define U_TILE_OFFSETS(TILE)                                                                             \
     {                                                                                                    \
         const int pix0_ = (TILE) * 128 + wave * 32 + 2 * q;                                              \
         const bool pvalid_ = pix0_ < a.M;                                                                \
+        if (TR) doff = pvalid_ ? (unsigned)pix0_ * (unsigned)cin4 + (unsigned)(c4 * 16) : 0x80000000u;  /* M even */ \
         const int pc_ = pvalid_ ? pix0_ : 0;                                                             \
         int b_, rem_, y_, x0_;                                                                           \
         fast_divmod(pc_, hw, inv_hw, b_, rem_);        /* pixel counts < 2^24 (checked by the launcher) */ \
@@ -918,7 +951,15 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         const int ngrp = cin / 4;
         for (int e = tid; e < 9 * ngrp; e += 256) {
             const int t = e / ngrp, g4 = e - t * ngrp;
-            reinterpret_cast<float4*>(sDW)[g4 * 9 + t] = reinterpret_cast<const float4*>(a.dw)[e];
+            reinterpret_cast<float4*>(sDW)[g4 * NTAP + t] = reinterpret_cast<const float4*>(a.dw)[e];
+        }
+        if (TR) for (int e = tid; e < 8 * NT; e += 256) sST[e] = 0.f;
+        if (tr_act) {   // "taps" 9 and 10 of a channel group: the scale and the shift of the input's BatchNorm + ReLU
+            for (int g4 = tid; g4 < ngrp; g4 += 256) {
+                const float4 q0 = a.tr_coef[4 * g4], q1 = a.tr_coef[4 * g4 + 1], q2 = a.tr_coef[4 * g4 + 2], q3 = a.tr_coef[4 * g4 + 3];
+                reinterpret_cast<float4*>(sDW)[g4 * NTAP + 9] = make_float4(q0.x, q1.x, q2.x, q3.x);
+                reinterpret_cast<float4*>(sDW)[g4 * NTAP + 10] = make_float4(q0.y, q1.y, q2.y, q3.y);
+            }
         }
     }
 
@@ -930,7 +971,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     const int h = lane >> 5, r32 = lane & 31;
     float bias_r[NTILES];   // loaded once: a global load inside the epilogue would sit on its critical path
 #pragma unroll
-    for (int n = 0; n < NTILES; ++n) bias_r[n] = a.bias[n0 + n * 32 + r32];
+    for (int n = 0; n < NTILES; ++n) bias_r[n] = TR ? 0.f : a.bias[n0 + n * 32 + r32];
     __syncthreads();   // depthwise taps visible
     U_STAMP(1)
 
@@ -972,6 +1013,13 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     {                                                                                                    \
         constexpr int buf = (P) & 1;   /* the steady loop is unrolled by two: buffer parities are static */ \
         float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;                                            \
+        if (tr_act) {   /* relu(z * sc + sh) of every window element; a NaN (the padding header) becomes 0 */ \
+            const float4 sc_ = *reinterpret_cast<const float4*>(twp + 36), sh_ = *reinterpret_cast<const float4*>(twp + 40);  \
+            _Pragma("unroll") for (int e = 0; e < NLD; ++e) {                                            \
+                RIN[e].x = fmaxf(fmaf(RIN[e].x, sc_.x, sh_.x), 0.f); RIN[e].y = fmaxf(fmaf(RIN[e].y, sc_.y, sh_.y), 0.f);  \
+                RIN[e].z = fmaxf(fmaf(RIN[e].z, sc_.z, sh_.z), 0.f); RIN[e].w = fmaxf(fmaf(RIN[e].w, sc_.w, sh_.w), 0.f);  \
+            }                                                                                            \
+        }                                                                                                \
         if (!(dbg & 2)) {                                                                                \
             const float* tw = twp;                                                                       \
             _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                             \
@@ -987,11 +1035,20 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         float* dA = sAw + buf * SAW + (2 * q) * LSTR + c4 * 4;                                           \
         *reinterpret_cast<float4*>(dA) = o0;                                                             \
         *reinterpret_cast<float4*>(dA + LSTR) = o1;                                                      \
+        if (d_out) {   /* the depthwise output, kept for the weight-gradient product: [pixel][cin] */     \
+            /* the chunk offset goes into the VECTOR offset, soffset stays the constant 0: a 16-byte buffer store \
+               with an SGPR soffset was seen to pick up the NEXT value written to its data registers (the voffset \
+               of the second store landed in D) -- the compiler only keeps the store-data wait state of gfx9 for \
+               an immediate soffset */                                                                   \
+            const unsigned dv_ = doff + (unsigned)st_kc * (KCH * 4);                                     \
+            buf_store16(o0, rs_d, dv_, 0u);                                                              \
+            buf_store16(o1, rs_d, dv_ + (unsigned)cin4, 0u);                                             \
+        }                                                                                                \
         if (NBI % 256 == 0 || NB4 > 1 || tid < NBI) *reinterpret_cast<float4*>(sB + buf * SB + bdst[0]) = rb0;  \
         if (NB4 > 1 && (NBI >= 512 || tid + 256 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 1 ? 1 : 0]) = rb1;  \
         if (NB4 > 2 && (NBI >= 768 || tid + 512 < NBI)) *reinterpret_cast<float4*>(sB + buf * SB + bdst[NB4 > 2 ? 2 : 0]) = rb2;  \
-        twp += 4 * 36;                                                                                   \
-        if (++st_kc == nchunks) { st_kc = 0; twp = sDW + c4 * 36; }                                      \
+        twp += 4 * (4 * NTAP);                                                                           \
+        if (++st_kc == nchunks) { st_kc = 0; twp = sDW + c4 * (4 * NTAP); }                              \
     }
 #define U_STAGE(P) U_STAGE2(P, rin)
     // global loads of the next position of the load cursor
@@ -1007,9 +1064,23 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     // not bytes).  Issued AFTER the iteration's prefetch loads: the memory counter retires in issue order, so
     // the next wait for those loads does not also wait for the stores' acknowledgements; the stores drain
     // while the next tile's chunks are multiplied.
+    // (inference: folded bias + ReLU; training: the raw product is this layer's pre-BatchNorm map)
+#define U_ACT(X) (TR ? (X) : relu_keep_nan(X))
 #define U_EPILOGUE()                                                                                     \
     {                                                                                                    \
         const int pw = mm_tile * 128 + wave * 32;                                                        \
+        if (TR) {   /* column sums of this lane's 16 rows (rows >= M are exact zeros), kept over the workgroup's tiles */ \
+            _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                         \
+                float s1 = 0.f, s2 = 0.f;                                                                \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) { const float z = acc[n][r]; s1 += z; s2 = fmaf(z, z, s2); }  \
+                s1 += __shfl_xor(s1, 32);                                                                \
+                s2 += __shfl_xor(s2, 32);                                                                \
+                if (h == 0) {   /* wave-private LDS row: no synchronisation (a wave's LDS operations execute in order) */ \
+                    sST[(wave * 2 + 0) * NT + n * 32 + r32] += s1;                                       \
+                    sST[(wave * 2 + 1) * NT + n * 32 + r32] += s2;                                       \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
         if (!(dbg & 4) && pw < a.M) {                                                                    \
             const int qi = lane & 3, qj = r32 >> 2;                                                      \
             float* dst = a.out + (size_t)(pw + 4 * h + qi) * a.ld_out + a.co_off + n0 + qj * 4;          \
@@ -1019,8 +1090,8 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
                 _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                     \
                     const float bvn = bias_r[n];                                                         \
                     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                      \
-                        float x0 = relu_keep_nan(acc[n][4 * g + 0] + bvn), x1 = relu_keep_nan(acc[n][4 * g + 1] + bvn);  \
-                        float x2 = relu_keep_nan(acc[n][4 * g + 2] + bvn), x3 = relu_keep_nan(acc[n][4 * g + 3] + bvn);  \
+                        float x0 = U_ACT(acc[n][4 * g + 0] + bvn), x1 = U_ACT(acc[n][4 * g + 1] + bvn);          \
+                        float x2 = U_ACT(acc[n][4 * g + 2] + bvn), x3 = U_ACT(acc[n][4 * g + 3] + bvn);          \
                         quad_transpose4(x0, x1, x2, x3, lane);                                           \
                         *reinterpret_cast<float4*>(dst + (8 * g) * ldo + n * 32) = make_float4(x0, x1, x2, x3);  \
                     }                                                                                    \
@@ -1029,8 +1100,8 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
                 _Pragma("unroll") for (int n = 0; n < NTILES; ++n) {                                     \
                     const float bvn = bias_r[n];                                                         \
                     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                      \
-                        float x0 = relu_keep_nan(acc[n][4 * g + 0] + bvn), x1 = relu_keep_nan(acc[n][4 * g + 1] + bvn);  \
-                        float x2 = relu_keep_nan(acc[n][4 * g + 2] + bvn), x3 = relu_keep_nan(acc[n][4 * g + 3] + bvn);  \
+                        float x0 = U_ACT(acc[n][4 * g + 0] + bvn), x1 = U_ACT(acc[n][4 * g + 1] + bvn);          \
+                        float x2 = U_ACT(acc[n][4 * g + 2] + bvn), x3 = U_ACT(acc[n][4 * g + 3] + bvn);          \
                         quad_transpose4(x0, x1, x2, x3, lane);                                           \
                         if (pw + 8 * g + 4 * h + qi < a.M)                                               \
                             *reinterpret_cast<float4*>(dst + (8 * g) * ldo + n * 32) = make_float4(x0, x1, x2, x3);  \
@@ -1044,7 +1115,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         mm_tile += GL;                                                                                   \
     }
 
-    const float* twp = sDW + c4 * 36;                  // this lane's tap vectors of the next chunk to stage
+    const float* twp = sDW + c4 * (4 * NTAP);          // this lane's tap vectors of the next chunk to stage
     const float* const cA0 = sAw + r32 * LSTR + h * (KCH / 2);                       // fragment read bases (PREC 1)
     const float* const cB0 = sB + r32 * 8 + ((h ^ ((r32 >> 3) & 1)) * 4);
     // prologue: stage position 0, issue the loads of position 1 (total >= 2)
@@ -1089,11 +1160,22 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     U_MFMA(1)
     ++mm_kc;
     U_EPILOGUE()
+    if (TR) {   // one statistics row per workgroup: [gridDim.x][2][n_total]; the four waves' sums added in a fixed order
+        __syncthreads();                               // every wave's sums are in its row
+        const float* red = sST;                        // [4 waves][2][NT]
+        if (tid < 2 * NT) {
+            const int which = tid / NT, col = tid % NT;
+            const float v = ((red[(0 * 2 + which) * NT + col] + red[(1 * 2 + which) * NT + col]) +
+                             red[(2 * 2 + which) * NT + col]) + red[(3 * 2 + which) * NT + col];
+            a.tr_stat[((size_t)blockIdx.x * 2 + which) * a.n_total + n0 + col] = v;
+        }
+    }
 #undef U_MFMA
 #undef U_STAGE
 #undef U_ISSUE
 #undef U_PH
 #undef U_EPILOGUE
+#undef U_ACT
 #undef U_LOAD_CHUNK
 #undef U_TILE_OFFSETS
     U_STAMP(3)
@@ -1121,6 +1203,56 @@ static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
         PP_LAUNCH("k_sep_u", (k_sep_u<NT, S, WPB, 1>), grid, dim3(256), 0, s, a, ntiles);
     else
         PP_LAUNCH("k_sep_u", (k_sep_u<NT, S, WPS, 0>), grid, dim3(256), 0, s, a, ntiles);
+}
+
+// Training-mode forward of one separable layer as ONE launch (SepTrainArgs, pp_common.h): depthwise (with the input's
+// BatchNorm + ReLU evaluated on the way in) -> A tile in LDS -> pointwise product with this step's weights as two
+// float16 pieces -> pre-BatchNorm map + statistics partials; the depthwise output is stored for the backward pass.
+// Returns the number of statistics rows written ([rows][2][cout]), or 0 when the shape is not one the kernel takes
+// (the caller then runs the separate depthwise and product kernels).
+int launch_sep_train(const SepTrainArgs& t, hipStream_t s) {
+#if PP_SPLIT_MODE != 1
+    (void)t; (void)s;
+    return 0;
+#else
+    const long long M = (long long)t.batch * t.out_h * t.out_w;
+    const long long in_bytes = (long long)t.batch * t.in_h * t.in_w * t.cin * 4;
+    if (t.cin % KC != 0 || t.cout % 32 != 0 || (t.stride != 1 && t.stride != 2) || t.out_w % 2 != 0 || M >= (1 << 24) ||
+        in_bytes >= (1ll << 31) - 4096 || M * t.cin * 4 >= (1ll << 31) - 4096 || t.cin > 256)
+        return 0;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = t.in; a.dw = t.dw; a.wt16 = t.wt16; a.n_total = t.cout; a.out = t.Z;
+    a.M = (int)M; a.in_h = t.in_h; a.in_w = t.in_w; a.cin = t.cin; a.px_h = t.out_h; a.px_w = t.out_w;
+    a.stride = t.stride; a.ld_out = t.cout; a.co_off = 0; a.cout = t.cout;
+    a.tr_coef = t.coef; a.tr_D = t.D; a.tr_stat = t.stat;
+    const int ntiles = (a.M + 127) / 128;
+    const int nt = (t.cout % 128 == 0) ? 128 : (t.cout % 64 == 0 ? 64 : 32);
+    const int ny = t.cout / nt;
+    const int wpb = (nt == 128) ? 2 : 3;
+    int slots = (g_num_cus * wpb) / ny;
+    int gx = ntiles < slots ? ntiles : slots;
+    gx = (gx + 7) & ~7;
+    const dim3 grid((unsigned)gx, ny);
+    const char* tg = t.tag ? t.tag : "k_sep_u_tr";
+    {   // measurement switches (wrong results): PP_TR_NOD=1 no depthwise-output store, PP_TR_NOACT=1 no activation on the way in
+        static int nod = -1, noact = -1;
+        if (nod < 0) { const char* e = getenv("PP_TR_NOD"); nod = (e && e[0] == '1') ? 1 : 0; }
+        if (noact < 0) { const char* e = getenv("PP_TR_NOACT"); noact = (e && e[0] == '1') ? 1 : 0; }
+        if (nod) a.tr_D = nullptr;
+        if (noact) a.tr_coef = nullptr;
+    }
+    if (t.stride == 1) {
+        if (nt == 128) PP_LAUNCH(tg, (k_sep_u<128, 1, 2, 1, 0, 1>), grid, dim3(256), 0, s, a, ntiles);
+        else if (nt == 64) PP_LAUNCH(tg, (k_sep_u<64, 1, 3, 1, 0, 1>), grid, dim3(256), 0, s, a, ntiles);
+        else PP_LAUNCH(tg, (k_sep_u<32, 1, 3, 1, 0, 1>), grid, dim3(256), 0, s, a, ntiles);
+    } else {
+        if (nt == 128) PP_LAUNCH(tg, (k_sep_u<128, 2, 2, 1, 0, 1>), grid, dim3(256), 0, s, a, ntiles);
+        else if (nt == 64) PP_LAUNCH(tg, (k_sep_u<64, 2, 3, 1, 0, 1>), grid, dim3(256), 0, s, a, ntiles);
+        else PP_LAUNCH(tg, (k_sep_u<32, 2, 3, 1, 0, 1>), grid, dim3(256), 0, s, a, ntiles);
+    }
+    return gx;          // one statistics row per workgroup of a channel column
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

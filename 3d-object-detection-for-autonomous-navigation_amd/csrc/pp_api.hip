@@ -1728,18 +1728,31 @@ int train_buffers(pp_engine* e) {
     A1(dalloc(e, &cx.pfn_nrows, (size_t)1));
     A1(dalloc(e, &cx.pfn_prefix, B + 1));
     A1(dalloc(e, &cx.pfn_rec, B * s.max_voxels * 2));
-    A1(dalloc(e, &cx.canvas, B * s.ny * s.nx * s.C));
+    // maps the fused forward kernel reads through a 3x3 window carry a PP_ZPAD_FLOATS header in front, the padding of
+    // the convolution: NaN-filled for the pre-BatchNorm maps (relu(NaN * sc + sh) evaluates to 0 on the vector unit,
+    // launch_sep_train), zero-filled for the tensors read as they are (canvas, block-final activations)
+    auto dalloc_hdr = [&](float** p, size_t count, int fill = 0xff) -> int {
+        float* raw = nullptr;
+        int r = dalloc(e, &raw, count + PP_ZPAD_FLOATS);
+        if (r == PP_OK && hipMemset(raw, fill, PP_ZPAD_FLOATS * sizeof(float)) != hipSuccess) r = PP_ERR_HIP;
+        *p = raw ? raw + PP_ZPAD_FLOATS : nullptr;
+        return r;
+    };
+    A1(dalloc_hdr(&cx.canvas, B * s.ny * s.nx * s.C, 0));
     A1(dalloc(e, &cx.dcanvas, B * s.ny * s.nx * s.C));
     size_t max_z = 1, max_d = 1;
-    cx.lbuf.assign(s.layers.size(), TrainLayerBuf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+    long pw16_words = 0;
+    cx.lbuf.assign(s.layers.size(), TrainLayerBuf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0});
     for (size_t i = 0; i < s.layers.size(); ++i) {
         const LayerDesc& l = s.layers[i];
         TrainLayerBuf& tb = cx.lbuf[i];
         if (l.kind == LAYER_SEP) {
             const size_t rows = B * l.out_h * l.out_w;
-            A1(dalloc(e, &tb.D, rows * l.cin)); A1(dalloc(e, &tb.Z, rows * l.cout));
+            A1(dalloc(e, &tb.D, rows * l.cin)); A1(dalloc_hdr(&tb.Z, rows * l.cout));
             // the activation tensor only where it is read as one: the layer in front of a transposed convolution
-            if (i + 1 < s.layers.size() && s.layers[i + 1].kind == LAYER_DECONV) A1(dalloc(e, &tb.A, rows * l.cout));
+            if (i + 1 < s.layers.size() && s.layers[i + 1].kind == LAYER_DECONV) A1(dalloc_hdr(&tb.A, rows * l.cout, 0));
+            tb.pw16_off = pw16_words;
+            pw16_words += (long)2 * l.cin * l.cout;
             A1(dalloc(e, &tb.dA, rows * l.cout));
             max_z = std::max(max_z, rows * l.cout); max_d = std::max(max_d, rows * l.cin);
         } else if (l.kind == LAYER_DECONV) {
@@ -1757,14 +1770,16 @@ int train_buffers(pp_engine* e) {
     A1(dalloc(e, &cx.dhead_w, (size_t)s.CC * PP_HEAD_COLS)); A1(dalloc(e, &cx.dhead_b, (size_t)2 * PP_HEAD_COLS));
     A1(dalloc(e, &cx.dZ, max_z)); A1(dalloc(e, &cx.dD, max_d));
     A1(dalloc(e, &cx.part, train_part_floats(s)));
-    {   // one [2][N] row per 64-row tile of the largest forward product
+    {   // one [2][N] row per 64-row tile of the largest forward product (per 32 rows for the fused separable launches)
         size_t need = 1;
         for (const LayerDesc& l : s.layers) {
-            if (l.kind == LAYER_SEP) need = std::max(need, (B * l.out_h * l.out_w + 63) / 64 * 2 * (size_t)l.cout);
+            if (l.kind == LAYER_SEP) need = std::max(need, (B * l.out_h * l.out_w + 127) / 128 * 4 * 2 * (size_t)l.cout);
             else if (l.kind == LAYER_DECONV) need = std::max(need, (B * l.in_h * l.in_w + 63) / 64 * 2 * (size_t)l.k * l.k * l.cout);
         }
         A1(dalloc(e, &cx.stat_part, need));
+        cx.stat_part_floats = (long)need;
     }
+    A1(dalloc(e, &cx.pw16, (size_t)std::max<long>(pw16_words, 8)));
     // split-K partial tiles + the regions of the step's deferred reductions (every weight gradient keeps its
     // partials until the end of the step): 64 MB at the reference's batch, 16 MB more per frame beyond 4
     cx.gemm_part_floats = std::max<long>(16l << 20, (long)B * (4l << 20));

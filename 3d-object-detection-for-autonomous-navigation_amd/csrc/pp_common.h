@@ -183,6 +183,21 @@ bool deconv_can_fuse_heads(const LayerDesc& L);
 bool layer_writes_cls_plane(const LayerDesc& L);   // does this layer's kernel leave the compact class-logit plane?
 bool sparse_input_supported(const LayerDesc& L, int batch);   // may L's input be a canvas with unwritten empty cells?
 std::string layer_kernel_name(const LayerDesc& L, int batch);  // template instantiation that runs L at this batch
+// training-mode forward of one separable layer (backbone.hip: k_sep_u<..., TR = 1>; called by train.hip)
+struct SepTrainArgs {
+    const float* in;             // input map [batch][in_h][in_w][cin] with a PP_ZPAD_FLOATS header in front: NaN-filled when
+                                 // `coef` is given (relu(NaN * sc + sh) = 0 is the padding), zero-filled otherwise
+    const float4* coef;          // [cin] (sc, sh, ., .) when `in` is a pre-BatchNorm map, NULL when it is an activation
+    const float* dw;             // depthwise kernel [3][3][cin]
+    const unsigned short* wt16;  // this step's pointwise kernel as two float16 pieces, [cin / 16][2][cout][16]
+    float* Z;                    // out: pre-BatchNorm map [rows][cout]
+    float* D;                    // out: depthwise output [rows][cin]
+    float* stat;                 // out: statistics partials [rows written][2][cout] (one row per workgroup; at most
+                                 // ceil(rows / 128) + 7 of them)
+    int batch, in_h, in_w, cin, out_h, out_w, cout, stride;
+    const char* tag;             // profiler name of the launch ("k_sep_u_tr:<layer>")
+};
+int launch_sep_train(const SepTrainArgs& t, hipStream_t s);   // rows of `stat` written, 0: shape not supported
 int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s,
                  int ablate = 0);  // returns 0 or PP_ERR_UNSUPPORTED
 

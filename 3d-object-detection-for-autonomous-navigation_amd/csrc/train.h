@@ -29,6 +29,7 @@ struct TrainLayerBuf {
     float* stats;   // [cout][2] batch mean, 1/sqrt(var + eps)
     float* sums;    // [2][cout] scratch of the reductions
     float4* coef;   // [cout] (sc, sh, inv, -mean * inv): act = z * sc + sh, zhat = z * inv + nmi (k_tr_bn_finalize)
+    long pw16_off;  // separable layers: offset (16-bit words) of the layer's split pointwise kernel in TrainCtx::pw16
 };
 
 struct TrainCtx {
@@ -66,6 +67,11 @@ struct TrainCtx {
     float* stat_part;    // BatchNorm statistics partials of the forward products: [row tiles][2][GEMM columns]
     float* gemm_part;    // split-K partial tiles
     long gemm_part_floats;
+    // fused training forward of the separable layers (k_sep_u<..., TR = 1>): every pointwise kernel of the step as two
+    // float16 pieces, [cin / 16][2][cout][16] per layer (k_tr_split_pw, once per step); NULL: not available.  The
+    // maps those launches read (canvas, Z of in-block layers, A of block-final ones) carry a NaN header in front.
+    unsigned short* pw16;
+    long stat_part_floats;
 };
 
 std::vector<TrainEntry> train_layout(const TrainShape& s, int64_t* n_params, int64_t* n_state);

@@ -561,12 +561,21 @@ static bool train_split_gemm() {
     return v == 1;
 }
 
+// profiler name of the next product launches ("k_tr_gemm2:<what>"; the profiler keeps the pointer: interned strings)
+static thread_local const char* g_gemm_tag = "k_tr_gemm2";
+static void gemm_tag(const std::string& what) {
+    static thread_local std::vector<std::string*> pool;
+    for (std::string* p : pool) if (*p == what) { g_gemm_tag = p->c_str(); return; }
+    pool.push_back(new std::string(what));
+    g_gemm_tag = pool.back()->c_str();
+}
+
 template <int WM, int WN, int KCH>
 static void launch_gemm2(const TGemm2& a2, bool akc, bool bkc, dim3 grid, hipStream_t s) {
-    if (akc && bkc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, true, true, KCH>), grid, dim3(256), 0, s, a2);
-    else if (akc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, true, false, KCH>), grid, dim3(256), 0, s, a2);
-    else if (bkc) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, false, true, KCH>), grid, dim3(256), 0, s, a2);
-    else PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2<WM, WN, false, false, KCH>), grid, dim3(256), 0, s, a2);
+    if (akc && bkc) PP_LAUNCH(g_gemm_tag, (k_tr_gemm2<WM, WN, true, true, KCH>), grid, dim3(256), 0, s, a2);
+    else if (akc) PP_LAUNCH(g_gemm_tag, (k_tr_gemm2<WM, WN, true, false, KCH>), grid, dim3(256), 0, s, a2);
+    else if (bkc) PP_LAUNCH(g_gemm_tag, (k_tr_gemm2<WM, WN, false, true, KCH>), grid, dim3(256), 0, s, a2);
+    else PP_LAUNCH(g_gemm_tag, (k_tr_gemm2<WM, WN, false, false, KCH>), grid, dim3(256), 0, s, a2);
 }
 
 // rows of the statistics partials a forward product leaves ([tiles][2][N]; 0: the split kernel did not run)
@@ -716,10 +725,10 @@ static void tr_gemm_pair(const TrainCtx& cx, const GemmCall& w, const GemmCall& 
             TGemm2 p2{g2, nullptr, (d.N + 63) / 64, (d.M + 63) / 64, n2};
             g_last_stat_tiles = 0;
             const dim3 grid((unsigned)(wg1 + wg2));
-            if (d.sbk == 1 && wide) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<true, 64>), grid, dim3(256), 0, cx.stream, p1, p2);
-            else if (d.sbk == 1) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<true, 32>), grid, dim3(256), 0, cx.stream, p1, p2);
-            else if (wide) PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<false, 64>), grid, dim3(256), 0, cx.stream, p1, p2);
-            else PP_LAUNCH("k_tr_gemm2", (k_tr_gemm2_pair<false, 32>), grid, dim3(256), 0, cx.stream, p1, p2);
+            if (d.sbk == 1 && wide) PP_LAUNCH(g_gemm_tag, (k_tr_gemm2_pair<true, 64>), grid, dim3(256), 0, cx.stream, p1, p2);
+            else if (d.sbk == 1) PP_LAUNCH(g_gemm_tag, (k_tr_gemm2_pair<true, 32>), grid, dim3(256), 0, cx.stream, p1, p2);
+            else if (wide) PP_LAUNCH(g_gemm_tag, (k_tr_gemm2_pair<false, 64>), grid, dim3(256), 0, cx.stream, p1, p2);
+            else PP_LAUNCH(g_gemm_tag, (k_tr_gemm2_pair<false, 32>), grid, dim3(256), 0, cx.stream, p1, p2);
             if (n1 > 1) gemm_finish_split(cx, w, g1, n1);                 // deferred: its region is now taken
             if (n2 > 1) gemm_finish_split(cx, d, g2, n2);                 // reduced at once (from behind that region)
             return;
@@ -1700,6 +1709,28 @@ __global__ __launch_bounds__(256) void k_tr_unpack_head_grads(const float* __res
     }
 }
 
+// This step's pointwise kernels as two float16 pieces each (hi = rne(w), mid = rne(w - hi)), in the operand layout
+// of the fused forward kernel (k_sep_u<..., TR = 1>): [cin / 16][piece][cout][16] per layer, from the Keras layout
+// [cin][cout] of the flat parameter buffer.  One launch for all separable layers.
+struct SplitPwJob { long src, dst; int cin, cout; long first; };     // src: floats into params; dst: 16-bit words; first: global pair index
+struct SplitPwTable { int n; long total; SplitPwJob job[32]; };
+__global__ __launch_bounds__(256) void k_tr_split_pw(const float* __restrict__ params, unsigned short* __restrict__ out, SplitPwTable t) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // one weight per thread
+    if (i >= t.total) return;
+    int j = 0;
+    while (j + 1 < t.n && i >= t.job[j + 1].first) ++j;
+    const SplitPwJob q = t.job[j];
+    const long e = i - q.first;
+    const int co = (int)(e % q.cout), ci = (int)(e / q.cout);                // consecutive threads: consecutive co (coalesced read)
+    const float w = params[q.src + e];
+    const _Float16 hf = (_Float16)w;
+    const _Float16 mf = (_Float16)(w - (float)hf);
+    const int kc = ci >> 4, cc = ci & 15;
+    unsigned short* d = out + q.dst + (((long)kc * 2) * q.cout + co) * 16 + cc;
+    d[0] = __builtin_bit_cast(unsigned short, hf);
+    d[(long)q.cout * 16] = __builtin_bit_cast(unsigned short, mf);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
@@ -1909,6 +1940,32 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
     PP_LAUNCH("k_tr_scatter", k_tr_scatter, dim3(blocks_for((long)B * ncanvas * (s.C / 4))), dim3(256), 0, cx.stream, cx.cellmap,
               (const float*)cx.pfn_feat, cx.canvas, B, s.nz, ncanvas, s.C, s.max_voxels);
 
+    // fused forward of the separable layers (depthwise + product + statistics in one launch, launch_sep_train): from
+    // PP_TRAIN_FUSED_MIN output pixels on (below that the layers are a handful of workgroups and the split-K product
+    // kernels are the shorter chain); PP_TRAIN_FUSED=0 turns it off
+    static int fused_on = -1;
+    static long fused_min = -1;
+    if (fused_on < 0) { const char* e = getenv("PP_TRAIN_FUSED"); fused_on = (e && e[0] == '0') ? 0 : 1; }
+    if (fused_min < 0) { const char* e = getenv("PP_TRAIN_FUSED_MIN"); fused_min = e ? atol(e) : 32768; }
+    bool fused = fused_on && cx.pw16 != nullptr;
+    if (fused) {
+        SplitPwTable t;
+        memset(&t, 0, sizeof(t));
+        int bi_ = 0, li_ = 0;
+        for (size_t i = 0; i < s.layers.size() && fused; ++i) {
+            const LayerDesc& l = s.layers[i];
+            if (l.kind == LAYER_SEP) {
+                if (t.n >= 32) { fused = false; break; }
+                const std::string pre = "rpn/block" + std::to_string(bi_ + 1) + "/" + std::to_string(li_);
+                t.job[t.n] = SplitPwJob{(long)(L.p(pre + "/pointwise_kernel") - params), cx.lbuf[i].pw16_off, l.cin, l.cout, t.total};
+                t.total += (long)l.cin * l.cout;
+                ++t.n; ++li_;
+            } else if (l.kind == LAYER_DECONV) { ++bi_; li_ = 0; }
+        }
+        if (fused && t.n > 0)
+            PP_LAUNCH("k_tr_split_pw", k_tr_split_pw, dim3(blocks_for(t.total)), dim3(256), 0, cx.stream, params, cx.pw16, t);
+    }
+
     // cur: what the next layer reads -- a tensor (cur_coef == NULL: the canvas, a block-final activation) or the
     // pre-BatchNorm map of an in-block layer with its coefficient table (the activation is evaluated by the reader)
     const float* cur = cx.canvas;
@@ -1920,6 +1977,22 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
         if (l.kind == LAYER_SEP) {
             const std::string pre = "rpn/block" + std::to_string(bi + 1) + "/" + std::to_string(li);
             const long rows = (long)B * l.out_h * l.out_w;
+            int stat_rows = 0;
+            if (fused && rows >= fused_min && ((rows + 127) / 128 + 8) * 2 * l.cout <= cx.stat_part_floats) {
+                SepTrainArgs t;
+                t.in = cur; t.coef = cur_coef; t.dw = L.p(pre + "/depthwise_kernel"); t.wt16 = cx.pw16 + tb.pw16_off;
+                t.Z = tb.Z; t.D = tb.D; t.stat = cx.stat_part;
+                t.batch = B; t.in_h = l.in_h; t.in_w = l.in_w; t.cin = l.cin; t.out_h = l.out_h; t.out_w = l.out_w;
+                t.cout = l.cout; t.stride = l.stride;
+                static thread_local std::string tags[64];     // (the profiler keeps the pointer)
+                std::string& tag = tags[i % 64];
+                tag = "k_sep_u_tr:block" + std::to_string(bi + 1) + "." + std::to_string(li);
+                t.tag = tag.c_str();
+                stat_rows = launch_sep_train(t, cx.stream);
+            }
+            if (stat_rows > 0) {
+                g_last_stat_tiles = stat_rows;
+            } else {
             static int dwp = -1;      // PP_TRAIN_DWFWD=0: the thread-per-output kernel everywhere (A/B measurements)
             if (dwp < 0) { const char* e = getenv("PP_TRAIN_DWFWD"); dwp = (e && e[0] == '0') ? 0 : 1; }
             const long nthr = rows * (l.cin / 4);
@@ -1935,8 +2008,10 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                           make_div((unsigned)l.out_h), make_div((unsigned)l.out_w), make_div((unsigned)(l.cin / 4)), l.cin,
                           l.stride, cur_coef);
             }
+            gemm_tag("k_tr_gemm2:fwd.block" + std::to_string(bi + 1) + "." + std::to_string(li));
             tr_gemm(cx, tb.D, l.cin, 1, L.p(pre + "/pointwise_kernel"), l.cout, 1, tb.Z, l.cout, (int)rows, l.cout, l.cin,
                     nullptr, 0, 1, cx.stat_part);
+            }
             // tb.A exists for the block-final layers only (the transposed convolution and the next block read it)
             bn_relu_forward(cx, tb.Z, rows, l.cout, L.p(pre + "/bn/gamma"), L.p(pre + "/bn/beta"), tb.stats, tb.coef,
                             L.s(pre + "/bn/moving_mean"), L.s(pre + "/bn/moving_variance"), 0.99f, tb.A, l.cout, 0, ident,
@@ -1950,6 +2025,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
             const int N = l.k * l.k * l.cout;
             if (cur_coef != nullptr) return PP_ERR_UNSUPPORTED;   // (a block always ends in a layer that keeps its activation)
             // Zs[m][tap * cout + co] = X[m][:] . K[tap][co][:]   (Keras Conv2DTranspose kernel [k, k, Cout, Cin])
+            gemm_tag("k_tr_gemm2:fwd.deconv" + std::to_string(bi + 1));
             tr_gemm(cx, cur, l.cin, 1, L.p(pre + "/kernel"), 1, l.cin, tb.Z, N, (int)m, N, l.cin, nullptr, 0, 1, cx.stat_part);
             const RowMap rm{l.k, l.in_h, l.in_w};
             bn_relu_forward(cx, tb.Z, m * l.k * l.k, l.cout, L.p(pre + "/bn/gamma"), L.p(pre + "/bn/beta"), tb.stats, tb.coef,
@@ -1965,6 +2041,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
     PP_LAUNCH("k_tr_pack_heads", k_tr_pack_heads, dim3(blocks_for((long)s.CC * PP_HEAD_COLS)), dim3(256), 0, cx.stream,
               L.p("rpn/conv_box/kernel"), L.p("rpn/conv_cls/kernel"), kd, L.p("rpn/conv_box/bias"), L.p("rpn/conv_cls/bias"), bd,
               s.CC, nb, nc, nd, cx.head_w, cx.head_b);
+    gemm_tag("k_tr_gemm2:fwd.heads");
     tr_gemm(cx, cx.cat, s.CC, 1, cx.head_w, PP_HEAD_COLS, 1, cx.head, PP_HEAD_COLS, (int)px, PP_HEAD_COLS, s.CC, cx.head_b, 0, 1);
     }   // forward
     if (!(phase & 2)) return PP_OK;
@@ -1978,6 +2055,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
 
     // ---------------- backward ----------------
     // heads: dWh = cat^T . dhead, dbias = column sums, dcat = dhead . Wh^T
+    gemm_tag("k_tr_gemm2:wgrad.heads");
     tr_gemm(cx, cx.cat, 1, s.CC, cx.dhead, PP_HEAD_COLS, 1, cx.dhead_w, PP_HEAD_COLS, s.CC, PP_HEAD_COLS, (int)px, nullptr, 0,
             wgrad_split(cx, s.CC, PP_HEAD_COLS, (int)px));      // (reduced at once: k_tr_unpack_head_grads reads it next)
     PP_LAUNCH("k_tr_colstats", k_tr_colstats, dim3(TR_NPART), dim3(256), 0, cx.stream, (const float*)cx.dhead, px, PP_HEAD_COLS,
@@ -1990,6 +2068,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                   cx.stream, (const float*)cx.dhead_w, (const float*)cx.dhead_b, s.CC, nb, nc, nd, L.g("rpn/conv_box/kernel"),
                   L.g("rpn/conv_cls/kernel"), gkd, L.g("rpn/conv_box/bias"), L.g("rpn/conv_cls/bias"), gbd);
     }
+    gemm_tag("k_tr_gemm2:dgrad.heads");
     tr_gemm(cx, cx.dhead, PP_HEAD_COLS, 1, cx.head_w, 1, PP_HEAD_COLS, cx.dcat, s.CC, (int)px, s.CC, PP_HEAD_COLS, nullptr, 0, 1);
 
     // blocks in reverse: the gradient of a block's output arrives from the next block's first layer (stored by
@@ -2017,6 +2096,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                          L.g(dpre + "/bn/gamma"), L.g(dpre + "/bn/beta"), cx.dZ);
         // dK[n][cin] = dZs^T . X     dX[m][cin] (+)= dZs . K
         float* dAct = cx.lbuf[last].dA;
+        gemm_tag("k_tr_gemm2:pair.deconv" + std::to_string(b + 1));
         tr_gemm_pair(cx,
                      GemmCall{cx.dZ, 1, N, Xd, d.cin, 1, L.g(dpre + "/kernel"), d.cin, N, d.cin, (int)m, nullptr, 0,
                               wgrad_split(cx, N, d.cin, (int)m), nullptr, true},
@@ -2035,6 +2115,7 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                              L.g(pre + "/bn/beta"), cx.dZ, sums_part, sums_pstride, sums_nparts);
             sums_part = nullptr;
             // dWp[cin][cout] = D^T . dZ      dD[rows][cin] = dZ . Wp^T
+            gemm_tag("k_tr_gemm2:pair.block" + std::to_string(b + 1) + "." + std::to_string(i - first_of_block[b]));
             tr_gemm_pair(cx,
                          GemmCall{tb.D, 1, l.cin, cx.dZ, l.cout, 1, L.g(pre + "/pointwise_kernel"), l.cout, l.cin, l.cout,
                                   (int)rows, nullptr, 0, wgrad_split(cx, l.cin, l.cout, (int)rows), nullptr, true},

@@ -328,7 +328,14 @@ def test_full_batch_properties(pp, engines):
         s = dets1[b]["score"][:k]
         assert (np.diff(s) <= 0).all(), "keep order is descending score"
         assert ((s > 0) & (s < 1)).all()
-        # NMS is idempotent: survivors do not suppress each other (AABB +1 IoU <= 0.5)
+        # NMS is idempotent: survivors do not suppress each other (stand-up AABB, `+1` IoU <= 0.5 for every kept pair;
+        # oracle arithmetic: libraries/eval_helper_functions.py:553-564 on load_data.py:1525-1593 corners)
+        if k > 1:
+            bx = dets1[b]["box3d_lidar"][:k]
+            aabb = rn.corner_to_standup(rn.center_to_corner_box2d(bx[:, :2], bx[:, 3:5], bx[:, 6]))
+            for i in range(k):
+                for j in range(i + 1, k):
+                    assert rn.nms_iou(aabb[i], aabb[j]) <= 0.5 + 1e-6, (b, i, j)
         P = im1["n_pillars"][b]
         assert 0 < P <= eng.d.max_voxels
         assert im1["num_points"][b, :P].min() >= 1 and im1["num_points"][b, :P].max() <= eng.d.max_points
