@@ -121,6 +121,8 @@ struct GemmArgs {
     int k, cout;          // deconv
     const int* occ;       // sparse input (k_sep_u<..., OCC = 1> / k_sep_k4): cell -> pillar map, see LayerDesc::d_occ
     int occ_nz;
+    const unsigned long long* occbits;   // the same occupancy as a bitmap (LayerDesc::d_occbits), or NULL: k_sep_u<..., OCC = 1>
+    int occ_w64;                         // reads three 64-bit windows per pixel pair instead of 3 x WW x nz map entries
     // last fused-head branch only: the finished class logits of every pixel also go to a compact plane
     // [pixels][cls_ncol] (head columns cls_col0 .. cls_col0 + cls_ncol), which is all the post-process reads
     // of the head map for its candidate scan (8 bytes per pixel instead of a 128-byte row); NULL: not written
@@ -884,15 +886,34 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
             colok_[dx_] = (unsigned)(xi_ + dx_) < (unsigned)a.in_w;                                      \
             coloff_[dx_] = (unsigned)((dx_ - 1) * cin4);                                                 \
         }                                                                                                \
+        /* OCC with the occupancy bitmap: bit (x + 1) of row y; this lane's window starts at bit xi_ + 1 >= 0 of   \
+           rows yi_ .. yi_ + 2 -- two 64-bit words per row (the row ends in a spare word) instead of one map entry  \
+           per window element and z-cell */                                                               \
+        unsigned wbits_[3] = {0u, 0u, 0u};                                                               \
+        const bool bits_ = OCC && a.occbits != nullptr;                /* uniform */                     \
+        if (bits_) {                                                                                     \
+            const unsigned long long* ob_ = a.occbits + (size_t)b_ * a.in_h * a.occ_w64;                 \
+            const int pos0_ = xi_ + 1, wi_ = pos0_ >> 6, sh_ = pos0_ & 63;                               \
+            _Pragma("unroll") for (int dy_ = 0; dy_ < 3; ++dy_) {                                        \
+                const int yy_ = min(max(yi_ + dy_, 0), a.in_h - 1);    /* (an out-of-map row is switched off by rowok_) */ \
+                const unsigned long long* r_ = ob_ + (size_t)yy_ * a.occ_w64 + wi_;                      \
+                const unsigned long long lo_ = r_[0], hi_ = r_[1];                                       \
+                wbits_[dy_] = (unsigned)((lo_ >> sh_) | ((hi_ << 1) << (63 - sh_)));                     \
+            }                                                                                            \
+        }                                                                                                \
         _Pragma("unroll") for (int e = 0; e < NLD; ++e) {                                                \
             const int dy_ = e / WW, dx_ = e % WW;                                                        \
             bool ok_ = rowok_[dy_] & colok_[dx_];                                                        \
             if (OCC) {                                                                                   \
-                bool occ_ = false;                                                                       \
-                const int cidx_ = ok_ ? (yi_ + dy_) * a.in_w + xi_ + dx_ : 0;                            \
-                for (int z_ = 0; z_ < a.occ_nz; ++z_)                                                    \
-                    occ_ = occ_ | (a.occ[(size_t)(b_ * a.occ_nz + z_) * (a.in_h * a.in_w) + cidx_] >= 0); \
-                ok_ = ok_ & occ_;                                                                        \
+                if (bits_) {                                                                             \
+                    ok_ = ok_ & (((wbits_[dy_] >> dx_) & 1u) != 0u);                                     \
+                } else {                                                                                 \
+                    bool occ_ = false;                                                                   \
+                    const int cidx_ = ok_ ? (yi_ + dy_) * a.in_w + xi_ + dx_ : 0;                        \
+                    for (int z_ = 0; z_ < a.occ_nz; ++z_)                                                \
+                        occ_ = occ_ | (a.occ[(size_t)(b_ * a.occ_nz + z_) * (a.in_h * a.in_w) + cidx_] >= 0); \
+                    ok_ = ok_ & occ_;                                                                    \
+                }                                                                                        \
             }                                                                                            \
             aoff[e] = (ok_ ? rowoff_[dy_] + coloff_[dx_] : 0u) + (unsigned)(c4 * 16);                    \
         }                                                                                                \
@@ -2645,6 +2666,8 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
     a.stride = L.stride; a.ld_out = L.ld_out; a.co_off = L.co_off;
     a.k = L.k; a.cout = L.cout;
     a.occ = L.d_occ; a.occ_nz = L.occ_nz;
+    a.occbits = L.d_occbits; a.occ_w64 = occ_words(L.in_w);
+    a.tr_coef = nullptr; a.tr_D = nullptr; a.tr_stat = nullptr;
     a.cls_plane = layer_writes_cls_plane(L) ? L.d_cls_plane : nullptr;
     a.cls_col0 = L.cls_col0; a.cls_ncol = L.cls_ncol;
     if (L.kind == LAYER_SEP) {

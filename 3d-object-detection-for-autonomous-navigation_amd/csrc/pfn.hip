@@ -242,7 +242,14 @@ __global__ __launch_bounds__(256) void k_pfn_canvas(PfnParams p) {
 #ifndef PFN2_CW
 #define PFN2_CW 8
 #endif
-template <int CPL, int F>
+// PIL (sparse canvas, round 4): PILLAR-centric ownership.  On a KITTI-shaped grid 2.7 % of the cells hold a pillar, and
+// the cell-centric launch above spent its time dispatching ~27 000 waves per frame of which nearly all read one line
+// of the cell map and left (199 us for 184 k pillars at B = 32).  Here a wave owns PFN2_CW consecutive PILLARS of the
+// voxeliser's list: lane c reads pillar c's cell; a pillar that is the lowest occupied z-cell of its (y, x) column
+// takes the whole column (its z-neighbours come from the cell map and are summed in z order, exactly as above), any
+// other pillar's slots stay empty; from the slot metadata on the kernel is the same stream walk.  Cells without a
+// pillar are never visited, let alone written.
+template <int CPL, int F, bool PIL = false>
 __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     constexpr int FA = F + 5;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -269,9 +276,10 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     // cell stride: waves per frame (NW * PFN2_CW >= ncanvas; the anchor-mask workgroup does not count) or 1
     const int bx = (int)blockIdx.x - amb;
     const int NW = p.sparse ? 1 : ((int)gridDim.x - amb) * 4;
-    const int wid = p.sparse ? (bx * 4 + wave) * PFN2_CW : bx * 4 + wave;   // first cell
-    if (wid >= ncanvas) return;
-    const int ncells = min(PFN2_CW, (ncanvas - wid + NW - 1) / NW);
+    const int wid = (PIL || p.sparse) ? (bx * 4 + wave) * PFN2_CW : bx * 4 + wave;   // first cell (PIL: first pillar)
+    const int np_frame = PIL ? p.npillars[b] : 0;
+    if (PIL ? (wid >= np_frame) : (wid >= ncanvas)) return;
+    const int ncells = PIL ? min(PFN2_CW, np_frame - wid) : min(PFN2_CW, (ncanvas - wid + NW - 1) / NW);
     const int nz = p.nz;
     const int NS = ncells * nz;                       // slots of this wave (<= 64, checked by the launcher)
     const int C = p.C, T = p.T;
@@ -283,10 +291,35 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     const int* ps = p.pillar_start + (size_t)b * (p.max_voxels + 1);
     int pid = -1, start = 0, cnt = 0, slot_cell = 0;
     float slot_cx = 0.f, slot_cy = 0.f;
-    if (lane < NS) {
-        const int c = lane / nz, z = lane - c * nz;
-        slot_cell = c;
-        pid = p.cellmap[((size_t)b * nz + z) * ncanvas + wid + c * NW];
+    [[maybe_unused]] int col_xy = 0;                  // PIL: lane c = the (y, x) cell of the wave's pillar c
+    if constexpr (PIL) {
+        int z0 = 0;
+        bool primary = false;
+        if (lane < ncells) {
+            const int cz = p.pillar_cell[(size_t)b * p.max_voxels + wid + lane];
+            z0 = cz / ncanvas;
+            col_xy = cz - z0 * ncanvas;
+            primary = true;                           // ... unless a lower z-cell of the column holds a pillar too
+            for (int z = 0; z < z0; ++z) primary = primary & (p.cellmap[((size_t)b * nz + z) * ncanvas + col_xy] < 0);
+            if (p.occbits != nullptr) {               // the column's bit of the frame's occupancy bitmap (bit x + 1 of row y)
+                const int yy = col_xy / p.nx, xx = col_xy - yy * p.nx;
+                atomicOr(p.occbits + ((size_t)b * p.ny + yy) * occ_words(p.nx) + ((xx + 1) >> 6), 1ull << ((xx + 1) & 63));
+            }
+        }
+        if (lane < NS) {
+            const int c = lane / nz, z = lane - c * nz;
+            slot_cell = c;
+            const int cxy = __shfl(col_xy, c), zc = __shfl(z0, c);
+            const bool prim = __shfl((int)primary, c) != 0;
+            if (prim && z == zc) pid = wid + c;
+            else if (prim && z > zc) pid = p.cellmap[((size_t)b * nz + z) * ncanvas + cxy];
+        }
+    } else {
+        if (lane < NS) {
+            const int c = lane / nz, z = lane - c * nz;
+            slot_cell = c;
+            pid = p.cellmap[((size_t)b * nz + z) * ncanvas + wid + c * NW];
+        }
     }
     // sparse canvas: most waves of a mostly empty grid have nothing to write -- leave before any other work
     if (p.sparse && __ballot(pid >= 0) == 0ull) return;
@@ -296,7 +329,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
             start = ps[pid];
             cnt = min(ps[pid + 1] - start, T);
         }
-        const int cell = wid + c * NW;
+        const int cell = PIL ? __shfl(col_xy, c) : wid + c * NW;
         const int yi = cell / p.nx, xi = cell - yi * p.nx;
         slot_cx = __fadd_rn(__fmul_rn((float)xi, p.vx), p.x_off);      // model/pointpillars.py:156-171
         slot_cy = __fadd_rn(__fmul_rn((float)yi, p.vy), p.y_off);
@@ -347,8 +380,8 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
     };
 
     // ---- (3) walk the stream ----
-    float* cbase = p.canvas + ((size_t)b * ncanvas + wid) * C;
-    const size_t cstep = (size_t)NW * C;              // floats between two cells of this wave
+    float* cbase = p.canvas + ((size_t)b * ncanvas + (PIL ? 0 : wid)) * C;
+    const size_t cstep = (size_t)NW * C;              // floats between two cells of this wave (PIL: unused)
     float acc[CPL], m[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) { acc[q] = 0.f; m[q] = -3.0e38f; }
@@ -359,7 +392,7 @@ __global__ __launch_bounds__(256) void k_pfn_canvas2(PfnParams p) {
         // sparse canvas: cells without a pillar are not written at all (the first layer looks the cell up in
         // the cell map and reads zeros); writing the zeros of an almost empty grid is most of the traffic
         if (ch_ok && (cell_dirty || !p.sparse)) {
-            float* dst = cbase + (size_t)c * cstep + ch0;
+            float* dst = PIL ? cbase + (size_t)__builtin_amdgcn_readlane(col_xy, c) * C + ch0 : cbase + (size_t)c * cstep + ch0;
             if constexpr (CPL == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             else if constexpr (CPL == 2) *reinterpret_cast<float2*>(dst) = make_float2(acc[0], acc[1]);
             else dst[0] = acc[0];
@@ -471,6 +504,19 @@ static bool pfn_first_generation() {
     return v == 1;
 }
 
+static bool pfn_cell_centric_sparse() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PP_PFN_SPARSE_CELLS"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+// does launch_pfn run the pillar-centric kernel (the one that sets the occupancy bitmap) for these parameters?
+static bool pfn_pillar_centric(const PfnParams& p, bool padded) {
+    return !padded && !p.with_distance && p.sparse && p.pillar_cell != nullptr && p.npillars != nullptr && PFN2_CW * p.nz <= 64 &&
+           !pfn_first_generation() && !pfn_cell_centric_sparse();
+}
+bool pfn_writes_occbits(const PfnParams& p, bool padded) { return pfn_pillar_centric(p, padded); }
+
 template <int CPL, int F>
 static void launch_pfn_t(const PfnParams& p, bool padded, hipStream_t s) {
     const int ncanvas = p.ny * p.nx;
@@ -480,6 +526,10 @@ static void launch_pfn_t(const PfnParams& p, bool padded, hipStream_t s) {
         else PP_LAUNCH("k_pfn_canvas", (k_pfn_canvas<CPL, F, false, true>), grid, dim3(256), 0, s, p);
     } else if (padded) {
         PP_LAUNCH("k_pfn_canvas", (k_pfn_canvas<CPL, F, true>), grid, dim3(256), 0, s, p);
+    } else if (pfn_pillar_centric(p, padded)) {
+        // sparse canvas: a wave per PFN2_CW pillars of the voxeliser's list (PP_PFN_SPARSE_CELLS=1: the cell-centric walk)
+        dim3 gridp((p.max_voxels + 4 * PFN2_CW - 1) / (4 * PFN2_CW), p.batch);
+        PP_LAUNCH("k_pfn_canvas2", (k_pfn_canvas2<CPL, F, true>), gridp, dim3(256), 0, s, p);
     } else if (PFN2_CW * p.nz <= 64 && !pfn_first_generation()) {
         dim3 grid2((ncanvas + 4 * PFN2_CW - 1) / (4 * PFN2_CW) + (p.am_mask != nullptr ? AM_PFN_BLOCKS : 0), p.batch);
         const size_t lds = (p.am_mask != nullptr) ? (size_t)p.ny * (p.nx | 1) * sizeof(int) : 0;

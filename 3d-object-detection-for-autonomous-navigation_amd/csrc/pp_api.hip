@@ -85,6 +85,9 @@ struct pp_engine {
     bool train_pending = false;           // ... which pp_train_step_wait has not collected yet
     float* d_head_grad = nullptr;
     int* d_integ = nullptr;
+    unsigned long long* d_occbits = nullptr;   // [B][ny][occ_words(nx)] occupancy bitmap of the sparse-canvas passes
+    bool occbits_live = false;                 // this pass's PFN launch wrote it (the pillar-centric kernel)
+    bool occbits_cleared = false;              // ... after this pass's k_cell_first cleared it
     uint8_t* d_mask = nullptr;
     float* d_anchors = nullptr;
     int* d_cells = nullptr;
@@ -405,7 +408,9 @@ int run_voxelize(pp_engine* e, int batch, int max_n) {
     {
         ProfScope ps(e, "k_cell_first");   // also clears the cell map
         launch_cell_first(e->d_points, e->d_offsets, batch, max_n, e->F, e->geom, e->d_cell, d_first, e->d_cellmap,
-                          e->zc ? e->d_feed[e->in_buf] : nullptr, e->d_points, e->d_offsets, e->stream);
+                          e->zc ? e->d_feed[e->in_buf] : nullptr, e->d_points, e->d_offsets, e->stream,
+                          e->sparse_canvas ? e->d_occbits : nullptr, e->ny * occ_words(e->nx));
+        e->occbits_cleared = e->sparse_canvas;
     }
     {
         ProfScope ps(e, "k_voxel_frame");
@@ -448,10 +453,17 @@ int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out, bool with_mas
     p.y_off = (float)(e->cfg.voxel_size[1] / 2 + e->cfg.pc_range[1]);
     p.w = e->d_pfn_w; p.bias = e->d_pfn_b; p.cellmap = e->d_cellmap;
     p.pts_sorted = e->d_points_sorted; p.offsets = e->d_offsets; p.pillar_start = e->d_pstart;
+    p.pillar_cell = e->d_pcell; p.npillars = e->d_npillars;
     p.voxels = e->d_voxels; p.num_points = e->d_numpts;
     p.canvas = e->d_canvas; p.feat_out = feat_out;
     p.sparse = e->sparse_canvas ? 1 : 0;
     p.with_distance = e->with_dist ? 1 : 0;
+    // the bitmap is only as good as its clearing: the fused path's k_cell_first does it (run_voxelize); the stage entry
+    // points build the cell map from the caller's coordinates and keep the cell-map lookups
+    p.occbits = (e->sparse_canvas && !padded && e->occbits_cleared) ? e->d_occbits : nullptr;
+    e->occbits_live = p.occbits != nullptr && pfn_writes_occbits(p, padded);
+    if (!e->occbits_live) p.occbits = nullptr;
+    e->occbits_cleared = false;
     e->mask_in_pfn = false;
     if (with_mask && batch <= anchor_mask_in_pfn_max_batch() && pfn_can_carry_anchor_mask(p, padded)) {
         // the anchor mask (needs the cell map only, read by the post-process only) rides in this launch
@@ -467,6 +479,14 @@ int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out, bool with_mas
 
 int run_anchor_mask(pp_engine* e, int batch) {
     ProfScope ps(e, nullptr);   // three kernels, each under its own name
+    static int bits = -1;       // PP_ANCHOR_MASK_BITS=0: the integral-image kernels on the sparse-canvas path too
+    if (bits < 0) { const char* s_ = getenv("PP_ANCHOR_MASK_BITS"); bits = (s_ && s_[0] == '0') ? 0 : 1; }
+    if (bits && e->occbits_live && e->nz == 1) {   // one z-cell: a bit of the occupancy bitmap is the pillar count
+        launch_anchor_mask_bits(e->d_occbits, batch, e->ny, e->nx, e->d_cells, e->A, e->cfg.anchor_area_threshold, e->d_mask,
+                                e->stream);
+        HIPCHK(e, hipGetLastError());
+        return PP_OK;
+    }
     launch_anchor_mask(e->d_cellmap, batch, e->nz, e->ny, e->nx, e->d_cells, e->A, e->cfg.anchor_area_threshold,
                        e->d_integ, e->d_mask, e->stream);
     HIPCHK(e, hipGetLastError());
@@ -485,7 +505,9 @@ int run_backbone(pp_engine* e, int batch) {
     e->cls_plane_live = false;
     for (const LayerDesc& L : e->layers) if (layer_writes_cls_plane(L)) e->cls_plane_live = true;
     for (size_t i = 0; i < e->layers.size(); ++i) {
-        const LayerDesc& L = e->layers[i];
+        LayerDesc L = e->layers[i];
+        // sparse first layer: the occupancy bitmap when this pass's PFN launch left one, else the cell map
+        if (i == 0 && L.d_occ != nullptr) L.d_occbits = e->occbits_live ? e->d_occbits : nullptr;
         ProfScope ps(e, e->layer_tags[i].c_str());
         int st = launch_layer(L, batch, e->d_head, e->stream);
         if (st) return fail(e, st, "layer %s: unsupported shape (cin=%d cout=%d)", L.name, L.cin, L.cout);
@@ -748,6 +770,7 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             A1(dalloc(q, &e->d_head, (size_t)e->B * HW * PP_HEAD_COLS));
             A1(dalloc(q, &e->d_cls, (size_t)e->B * HW * e->napl * e->ncls));
             A1(dalloc(q, &e->d_integ, (size_t)e->B * e->ny * e->nx));
+            A1(dalloc(q, &e->d_occbits, (size_t)e->B * e->ny * occ_words(e->nx)));
             A1(dalloc(q, &e->d_mask, (size_t)e->B * e->A));
             A1(dalloc(q, &e->d_anchors, (size_t)e->A * 7));
             A1(dalloc(q, &e->d_cells, (size_t)e->A * 4));

@@ -112,6 +112,9 @@ struct LayerDesc {
     // cell holds no pillar is read from the zero header instead of the (unwritten) canvas.  NULL: dense input
     const int* d_occ;
     int occ_nz;
+    // the same occupancy as a bitmap (PfnParams::occbits), when this pass's PFN launch wrote it: three 16-byte-free
+    // lookups per window instead of one per window element and z-cell.  NULL: the cell map is consulted
+    const unsigned long long* d_occbits;
     // compact class-logit plane [B * H' * W'][cls_ncol], written by the LAST fused-head deconv (NULL elsewhere)
     float* d_cls_plane;
     int cls_col0, cls_ncol;
@@ -127,9 +130,10 @@ struct PpFeed {
     int pad_[2];
     int offsets[1];          // [batch + 1] follow
 };
+// (occbits != NULL: the frames' occupancy bitmaps, occ_n 64-bit words each, are cleared by the same launch)
 void launch_cell_first(const float* pts, const int* offsets, int batch, int max_n, int F, const VoxGeom& g,
                        int* cell, int* first, int* cellmap, const PpFeed* feed, float* pts_dst, int* offsets_dst,
-                       hipStream_t s);
+                       hipStream_t s, unsigned long long* occbits = nullptr, int occ_n = 0);
 // returns (through *sorted_in_b) nothing; the host derives the final buffer from voxel_sort_passes()
 int voxel_sort_passes(int max_voxels);
 bool voxel_first_in_lds(int max_n, int ncell, int max_voxels);   // pass first = NULL to both launchers below
@@ -158,6 +162,13 @@ struct PfnParams {
     const float* pts_sorted;
     const int* offsets;
     const int* pillar_start;
+    // pillar-centric launch (sparse canvas): linear (z, y, x) cell of every pillar [batch][max_voxels], pillars per frame [batch]
+    const int* pillar_cell;
+    const int* npillars;
+    // ... which also leaves the frame's occupancy bitmap (occ_words(nx) 64-bit words per grid row, bit x + 1 of a row
+    // = "a pillar in column x, any z"; cleared by k_cell_first): what the sparse first layer and the one-launch
+    // anchor mask read instead of the cell map.  NULL: not written
+    unsigned long long* occbits;
     // padded source (compat)
     const float* voxels;
     const int* num_points;
@@ -173,11 +184,18 @@ struct PfnParams {
     float am_threshold;
     uint8_t* am_mask;      // [batch][A]
 };
-bool pfn_can_carry_anchor_mask(const PfnParams& p, bool padded_source);   // would launch_pfn run the extra workgroups?
+bool pfn_can_carry_anchor_mask(const PfnParams& p, bool padded_source);
+bool pfn_writes_occbits(const PfnParams& p, bool padded_source);           // would launch_pfn's kernel set PfnParams::occbits?   // would launch_pfn run the extra workgroups?
 int launch_pfn(const PfnParams& p, bool padded_source, hipStream_t s);  // returns 0 or PP_ERR_UNSUPPORTED
 
 void launch_anchor_mask(const int* cellmap, int batch, int nz, int ny, int nx, const int* cells, int64_t A,
                         float threshold, int* integ, uint8_t* mask, hipStream_t s);
+// 64-bit words per grid row of the occupancy bitmap: bits 0 .. nx + 1 (bit x + 1 = column x; bit 0 = the padding
+// column x = -1) plus one spare word, so that a reader may always fetch the word after the one its window starts in
+__host__ __device__ static inline int occ_words(int nx) { return (nx + 2 + 63) / 64 + 1; }
+// the anchor mask from the occupancy bitmap (nz == 1 grids: a bit is a count): one launch, no integral image
+void launch_anchor_mask_bits(const unsigned long long* occbits, int batch, int ny, int nx, const int* cells, int64_t A,
+                             float threshold, uint8_t* mask, hipStream_t s);
 
 bool deconv_can_fuse_heads(const LayerDesc& L);
 bool layer_writes_cls_plane(const LayerDesc& L);   // does this layer's kernel leave the compact class-logit plane?

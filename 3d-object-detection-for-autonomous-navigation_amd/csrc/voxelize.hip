@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void k_cell_first(const float* __restrict__ pt
                                                     const int* __restrict__ offsets, int F, VoxGeom g,
                                                     int* __restrict__ cell, int* __restrict__ first,
                                                     int* __restrict__ cellmap, const PpFeed* __restrict__ feed,
-                                                    float* __restrict__ pts_dst, int* __restrict__ offsets_dst) {
+                                                    float* __restrict__ pts_dst, int* __restrict__ offsets_dst,
+                                                    unsigned long long* __restrict__ occbits, int occ_n) {
     const int b = blockIdx.y;
     if (feed != nullptr) {   // zero-copy feed: host-resident offsets / points, device copies for the later kernels
         offsets = feed->offsets;
@@ -55,6 +56,9 @@ __global__ __launch_bounds__(256) void k_cell_first(const float* __restrict__ pt
     // first to write it): one launch less than a separate memset node
     if (cellmap != nullptr)
         for (int e = blockIdx.x * 256 + threadIdx.x; e < g.ncell; e += gridDim.x * 256) cellmap[(size_t)b * g.ncell + e] = -1;
+    // ... and so is its occupancy bitmap (the pillar-centric PFN launch sets the bits)
+    if (occbits != nullptr)
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < occ_n; e += gridDim.x * 256) occbits[(size_t)b * occ_n + e] = 0ull;
     const int n0 = offsets[b];
     const int n1 = offsets[b + 1];
     const int n = n1 - n0;
@@ -587,11 +591,11 @@ bool voxel_first_in_lds(int max_n, int ncell, int max_voxels) {
 
 void launch_cell_first(const float* pts, const int* offsets, int batch, int max_n, int F, const VoxGeom& g,
                        int* cell, int* first, int* cellmap, const PpFeed* feed, float* pts_dst, int* offsets_dst,
-                       hipStream_t s) {
+                       hipStream_t s, unsigned long long* occbits, int occ_n) {
     if (batch <= 0) return;
     dim3 grid(max_n > 0 ? (max_n + 255) / 256 : 1, batch);   // at least one block per frame: it clears the cell map
     PP_LAUNCH("k_cell_first", k_cell_first, grid, dim3(256), 0, s, pts, offsets, F, g, cell, first, cellmap, feed, pts_dst,
-              offsets_dst);
+              offsets_dst, occbits, occ_n);
 }
 
 void launch_voxel_frame(const int* offsets, const int* cell, const int* first, int* cellmap, unsigned* keyA,

@@ -707,3 +707,34 @@ def test_predict_stage_call_reports_non_finite_head_maps(pp, hip_lib):
     with pytest.raises(pp.NumericError):
         eng.predict(box, cls, dr, mask, rect[None], trv[None])
     eng.close()
+
+
+@pytest.mark.parametrize("order", ["random", "ascending"])
+def test_predict_more_candidates_than_the_lds_buffer(pp, hip_lib, order):
+    """107 136 anchors per frame (KITTI-shaped grid), every one a candidate: nine times what k_postprocess keeps in LDS.
+    "random": the bound from the first 12 288 candidates leaves a few hundred keys for the in-LDS select (round 4);
+    "ascending": logits grow with the anchor index, the bound keeps nearly everything and the select falls back to
+    re-reading the head map per pass.  Both against the numpy oracle (model/voxelnet.py:1105-1379)."""
+    cfg = pp.config.kitti_shaped_config(1, num_class=2)
+    eng = pp.Engine(cfg, max_batch=1, max_points_per_frame=4096)
+    d = eng.d
+    A, H, W, k = d.num_anchors, d.head_h, d.head_w, d.num_anchor_per_loc
+    assert A > 8 * 12288
+    rng = np.random.default_rng(11)
+    box = (rng.standard_normal((1, H, W, k * 7)) * 0.2).astype(np.float32)
+    dr = rng.standard_normal((1, H, W, k * 2)).astype(np.float32)
+    if order == "random":
+        cls = (rng.standard_normal((1, H, W, k * d.num_class)) * 1.5 - 1.0).astype(np.float32)
+    else:   # anchor a's best class logit = -6 + 8 a / A (+ a little noise below the step between neighbours' classes)
+        base = -6.0 + 8.0 * np.arange(A, dtype=np.float64) / A
+        cls = np.stack([base, base - 1.0], axis=1).astype(np.float32).reshape(1, H, W, k * d.num_class)
+    mask = np.ones((1, A), np.uint8)
+    rect, trv, _ = pp.synth.default_calib()
+    dets, n = eng.predict(box, cls, dr, mask, rect[None], trv[None])
+    ex = (None, None, None, rect[None], trv[None], None, eng.anchors[None], mask, np.array([0]), None)
+    ref = rn.predict(ex, {"box_preds": box, "cls_preds": cls, "dir_cls_preds": dr}, d.nms_dict())[0]
+    assert ref["scores"] is not None and n[0] == len(ref["scores"]) > 0
+    np.testing.assert_allclose(dets[0]["score"][:n[0]], ref["scores"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dets[0]["box3d_lidar"][:n[0]], ref["box3d_lidar"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(dets[0]["label"][:n[0]], ref["label_preds"])
+    eng.close()
