@@ -580,10 +580,16 @@ static void launch_gemm2(const TGemm2& a2, bool akc, bool bkc, dim3 grid, hipStr
 
 // rows of the statistics partials a forward product leaves ([tiles][2][N]; 0: the split kernel did not run)
 static thread_local int g_last_stat_tiles = 0;
+static const int g_num_cus_train = 256;      // (MI355X; only a threshold for the tile choice below)
 
 // a launch with fewer workgroups than this lives on memory latency, not on throughput: 64-wide K chunks (half the
 // dependent load -> LDS -> MFMA rounds), and the two gradient products of a layer share one launch
-#define TR_LATENCY_WGS 512
+static long tr_latency_wgs() {      // PP_TRAIN_LATENCY_WGS (A/B measurements)
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("PP_TRAIN_LATENCY_WGS"); v = e ? atol(e) : 512; }
+    return v;
+}
+#define TR_LATENCY_WGS tr_latency_wgs()
 // PP_TRAIN_WIDE=0: 32-wide chunks everywhere (A/B measurements)
 static bool wide_enabled() {
     static int v = -1;
@@ -659,7 +665,15 @@ static void tr_gemm(const TrainCtx& cx, const GemmCall& c) {
         const long tall = (long)((M + 127) / 128) * ((N + 63) / 64) * ksplit;
         static long thr = -1;
         if (thr < 0) { const char* e = getenv("PP_TRAIN_TILE_THR"); thr = e ? atol(e) : (1l << 40); }
-        if (N >= 128 && M > 64 && big >= thr) {
+        // ... except for the products that are bound by the matrix pipe, not by memory: a long K against few bytes per
+        // output (the transposed convolutions' forward and input-gradient products at a full-chip batch).  There the
+        // 128 x 128 tile reads each LDS fragment for two accumulator tiles (PP_TRAIN_BIG_FLOPB: least FLOPs per byte of
+        // operand + result traffic for the large tile; 0 = never)
+        static double big_fb = -1.0;
+        if (big_fb < 0) { const char* e = getenv("PP_TRAIN_BIG_FLOPB"); big_fb = e ? atof(e) : 0.0; }
+        const double flop_per_byte = 2.0 * M * (double)N * K / (4.0 * ((double)M * K + (double)K * N + (double)M * N));
+        const bool compute_bound = big_fb > 0.0 && flop_per_byte >= big_fb && big >= 2 * g_num_cus_train && ksplit == 1;
+        if (N >= 128 && M > 64 && (big >= thr || compute_bound)) {
             dim3 grid((N + 127) / 128, (M + 127) / 128, ksplit);
             if (a2.stat_part) g_last_stat_tiles = (int)grid.y;
             launch_gemm2<2, 2, 32>(a2, akc, bkc, grid, cx.stream);
