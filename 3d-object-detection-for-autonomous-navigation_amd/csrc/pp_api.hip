@@ -1750,7 +1750,7 @@ int train_buffers(pp_engine* e) {
     A1(dalloc(e, &cx.pfn_sums, (size_t)2 * s.C));
     A1(dalloc(e, &cx.pfn_nrows, (size_t)1));
     A1(dalloc(e, &cx.pfn_prefix, B + 1));
-    A1(dalloc(e, &cx.pfn_rec, B * s.max_voxels * 2));
+    A1(dalloc(e, &cx.pfn_rec, B * s.max_voxels * 3));
     // maps the fused forward kernel reads through a 3x3 window carry a PP_ZPAD_FLOATS header in front, the padding of
     // the convolution: NaN-filled for the pre-BatchNorm maps (relu(NaN * sc + sh) evaluates to 0 on the vector unit,
     // launch_sep_train), zero-filled for the tensors read as they are (canvas, block-final activations)

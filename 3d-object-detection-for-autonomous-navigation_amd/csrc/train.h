@@ -48,7 +48,7 @@ struct TrainCtx {
     float* pfn_sums;     // [2][C]
     float* pfn_nrows;    // [1] rows of the padded PFN tensor (pillars of the batch * T), computed on the device
     int* pfn_prefix;     // [B + 1] exclusive prefix of the frames' pillar counts
-    float4* pfn_rec;     // [B * max_voxels][2] pillar records (row range, slot, cell | mean): written by k_tr_pfn_lin
+    float4* pfn_rec;     // [B * max_voxels][3] pillar records (row range, slot, canvas row | mean, centre): written by k_tr_pfn_lin
     float* canvas;       // [B][ny][nx][C]
     float* dcanvas;
     // RPN

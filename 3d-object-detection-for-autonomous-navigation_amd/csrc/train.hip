@@ -1423,25 +1423,67 @@ __device__ __forceinline__ void pillar_head(const PfnT& p, int gp, int lane, int
 __device__ __forceinline__ void pillar_record_store(const PfnT& p, int gp, const PillarHead& h, int lane) {
     if (lane != 0) return;
     const int cell = p.pillar_cell[(size_t)h.b * p.max_voxels + h.pid];
-    p.rec[2 * (size_t)gp] = make_float4(__int_as_float((int)h.row0), __int_as_float(h.n),
-                                        __int_as_float(h.b * p.max_voxels + h.pid), __int_as_float(cell));
-    p.rec[2 * (size_t)gp + 1] = make_float4(h.mx, h.my, h.mz, 0.f);
+    // (row0, n, frame * max_voxels + pillar, canvas row = frame * ny * nx + y * nx + x), (mean x y z, centre x), (centre y):
+    // the readers do no index arithmetic (three integer divisions per pillar and kernel in the first version)
+    const int ncanvas = p.nx * p.ny;
+    p.rec[3 * (size_t)gp] = make_float4(__int_as_float((int)h.row0), __int_as_float(h.n),
+                                        __int_as_float(h.b * p.max_voxels + h.pid), __int_as_float(h.b * ncanvas + cell % ncanvas));
+    p.rec[3 * (size_t)gp + 1] = make_float4(h.mx, h.my, h.mz, h.cx);
+    p.rec[3 * (size_t)gp + 2] = make_float4(h.cy, 0.f, 0.f, 0.f);
 }
-struct PillarRec { int n, slot, cellxy; long row0; float mx, my, mz, cx, cy; PtsBatch first; };
+struct PillarRec { int n, slot, crow; long row0; float mx, my, mz, cx, cy; PtsBatch first; };   // crow: the pillar's canvas row
+// Round 4: the record-based kernels walk their pillars through a two-stage software pipeline -- while pillar i is
+// computed the first point batch of pillar i + 1 is in flight (its address needs that pillar's record) and so is the
+// record of pillar i + 2.  A wave has ~13 pillars of ~5 points each: processed one by one, every pillar was a chain of
+// two dependent memory round trips with a few hundred instructions of work behind it, and the kernels took 70-120 us
+// for ~15 us of arithmetic.
+struct PillarRecRaw { float4 r0, r1; float cy; };
+__device__ __forceinline__ PillarRecRaw pillar_record_issue(const PfnT& p, int gp) {
+    PillarRecRaw r;
+    r.r0 = p.rec[3 * (size_t)gp];
+    r.r1 = p.rec[3 * (size_t)gp + 1];
+    r.cy = p.rec[3 * (size_t)gp + 2].x;
+    return r;
+}
+__device__ __forceinline__ void pillar_record_finish(const PfnT& p, const PillarRecRaw& raw, int lane, PillarRec& o);
 __device__ __forceinline__ void pillar_record_load(const PfnT& p, int gp, int lane, PillarRec& o) {
-    const float4 r0 = p.rec[2 * (size_t)gp], r1 = p.rec[2 * (size_t)gp + 1];
+    pillar_record_finish(p, pillar_record_issue(p, gp), lane, o);
+}
+__device__ __forceinline__ void pillar_record_finish(const PfnT& p, const PillarRecRaw& raw, int lane, PillarRec& o) {
+    const float4 r0 = raw.r0, r1 = raw.r1;
     o.row0 = (long)__builtin_amdgcn_readfirstlane(__float_as_int(r0.x));
     o.n = __builtin_amdgcn_readfirstlane(__float_as_int(r0.y));
     o.slot = __builtin_amdgcn_readfirstlane(__float_as_int(r0.z));
-    const int cell = __builtin_amdgcn_readfirstlane(__float_as_int(r0.w));
+    o.crow = __builtin_amdgcn_readfirstlane(__float_as_int(r0.w));
     o.first = pfn_load_batch(p, o.row0, o.n, 0, lane);
     o.mx = r1.x; o.my = r1.y; o.mz = r1.z;
-    const int ncanvas = p.nx * p.ny;
-    o.cellxy = cell % ncanvas;                                  // (y, x): the z index drops out
-    const int xi = cell % p.nx, yi = (cell / p.nx) % p.ny;
-    o.cx = __fadd_rn(__fmul_rn((float)xi, p.vx), p.x_off);      // model/pointpillars.py:156-171
-    o.cy = __fadd_rn(__fmul_rn((float)yi, p.vy), p.y_off);
+    o.cx = r1.w; o.cy = raw.cy;                                 // model/pointpillars.py:156-171, evaluated by k_tr_pfn_lin
 }
+// for (every pillar of this wave) body(h), h = its record with the first point batch loaded -- pipelined as above.
+// prefetch(hn) starts the loads of the NEXT pillar that depend on its record; take() moves what they returned into the
+// current pillar's variables (called before the next prefetch overwrites them).
+template <class Pre, class Take, class Body>
+__device__ __forceinline__ void pfn_for_pillars(const PfnT& p, int total, int lane, int wave, Pre&& prefetch, Take&& take,
+                                                Body&& body) {
+    const int stride = (int)gridDim.x * 4;
+    int gp = (int)blockIdx.x * 4 + wave;
+    if (gp >= total) return;
+    PillarRec h, hn;
+    pillar_record_finish(p, pillar_record_issue(p, gp), lane, hn);
+    prefetch(hn);
+    PillarRecRaw raw = pillar_record_issue(p, min(gp + stride, total - 1));
+    for (; gp < total; gp += stride) {
+        h = hn;
+        take();
+        if (gp + stride < total) {
+            pillar_record_finish(p, raw, lane, hn);
+            prefetch(hn);
+            raw = pillar_record_issue(p, min(gp + 2 * stride, total - 1));
+        }
+        body(h);
+    }
+}
+
 // y[q] = features . W[:, lane * CPL + q] (rows >= FA of w are zero)
 template <int CPL>
 __device__ __forceinline__ void pfn_dense(const float (&f)[10], const float (&w)[10][CPL], float (&y)[CPL]) {
@@ -1453,6 +1495,83 @@ __device__ __forceinline__ void pfn_dense(const float (&f)[10], const float (&w)
         y[q] = v;
     }
 }
+// Round 4: the Dense row in FOLDED form.  The layer is linear in the decorated features, so with pillar-local
+// coordinates x' = x - centre_x, y' = y - centre_y (the reference's f_center features: small numbers)
+//   y = (w0 + w4 + w7) x' + (w1 + w5 + w8) y' + (w2 + w6) z + w3 i + w9 |p|  +  K,
+//   K = w0 cx + w1 cy - w4 (mean_x - cx) - w5 (mean_y - cy) - w6 mean_z          (one constant per pillar and channel)
+// -- five FMAs per point and channel instead of ten (the inference kernel's arithmetic, pfn.hip; canonical feature
+// order: x y z | i | xyz - mean | xy - centre | norm).  The SAME chain runs in all four training kernels, so the
+// statistics, the max and the gradients see bit-identical values, as before.  The Dense-kernel gradient folds the same
+// way: per pillar S0 = sum dy, Sx' = sum x' dy, ... (six FMAs per point and channel instead of ten) and
+//   dw0 += Sx' + cx S0, dw4 += Sx' - (mean_x - cx) S0, dw7 += Sx', (y alike), dw2 += Sz, dw6 += Sz - mean_z S0, ...
+// with no large-coordinate cancellation (x', y' are within a pillar).
+template <int CPL>
+struct PfnFold {
+    float wsx[CPL], wsy[CPL], wsz[CPL], wi[CPL], wn[CPL];     // per-point weights
+    float w0[CPL], w1[CPL], w4[CPL], w5[CPL], w6[CPL];        // the pillar constant's weights
+};
+template <int CPL>
+__device__ __forceinline__ void pfn_fold(const float (&w)[10][CPL], PfnFold<CPL>& o) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        o.wsx[q] = (w[0][q] + w[4][q]) + w[7][q];
+        o.wsy[q] = (w[1][q] + w[5][q]) + w[8][q];
+        o.wsz[q] = w[2][q] + w[6][q];
+        o.wi[q] = w[3][q];
+        o.wn[q] = w[9][q];
+        o.w0[q] = w[0][q]; o.w1[q] = w[1][q]; o.w4[q] = w[4][q]; o.w5[q] = w[5][q]; o.w6[q] = w[6][q];
+    }
+}
+// K[q] of a pillar (wave-uniform geometry, this lane's channels)
+template <int CPL>
+__device__ __forceinline__ void pfn_pillar_const(const PfnFold<CPL>& o, float cx, float cy, float mx, float my, float mz,
+                                                 float (&K)[CPL]) {
+    const float dmx = mx - cx, dmy = my - cy;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        float k = cx * o.w0[q];
+        k = fmaf(cy, o.w1[q], k);
+        k = fmaf(-dmx, o.w4[q], k);
+        k = fmaf(-dmy, o.w5[q], k);
+        k = fmaf(-mz, o.w6[q], k);
+        K[q] = k;
+    }
+}
+// the point's coordinates in the form the folded chain takes them (wave-uniform): x', y', z, intensity, norm
+struct PfnPt { float xl, yl, z, it, nrm; };
+__device__ __forceinline__ PfnPt pfn_point(const PfnT& p, float x, float y, float z, float it, float cx, float cy) {
+    PfnPt o;
+    o.xl = x - cx; o.yl = y - cy; o.z = z; o.it = it;
+    o.nrm = 0.f;
+    if (p.with_distance) o.nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));   // (uniform branch)
+    return o;
+}
+template <int CPL>
+__device__ __forceinline__ void pfn_y(const PfnFold<CPL>& o, const PfnPt& t, const float (&K)[CPL], float (&y)[CPL]) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        float v = K[q];
+        v = fmaf(t.xl, o.wsx[q], v);
+        v = fmaf(t.yl, o.wsy[q], v);
+        v = fmaf(t.z, o.wsz[q], v);
+        v = fmaf(t.it, o.wi[q], v);       // (exact no-ops when the cloud has no intensity / the layer no norm feature:
+        v = fmaf(t.nrm, o.wn[q], v);      //  those rows of the folded weights are zero)
+        y[q] = v;
+    }
+}
+// for (every point j of the pillar) { pt = its folded-form coordinates (wave-uniform); BODY }
+#define PFN_FOR_POINTS2(P, H, LANE, BODY)                                                                \
+    for (int j0_ = 0; j0_ < (H).n; j0_ += 64) {                                                          \
+        const PtsBatch bt_ = (j0_ == 0) ? (H).first : pfn_load_batch((P), (H).row0, (H).n, j0_, (LANE)); \
+        const int cnt_ = min(64, (H).n - j0_);                                                           \
+        for (int jj_ = 0; jj_ < cnt_; ++jj_) {                                                           \
+            const int j = j0_ + jj_;                                                                     \
+            const PfnPt pt = pfn_point((P), pfn_bcast(bt_.x, jj_), pfn_bcast(bt_.y, jj_), pfn_bcast(bt_.z, jj_), \
+                                       pfn_bcast(bt_.it, jj_), (H).cx, (H).cy);                          \
+            BODY                                                                                         \
+        }                                                                                                \
+    }
+
 // for (every point j of the pillar) { f = its features (wave-uniform); BODY }
 #define PFN_FOR_POINTS(P, H, LANE, BODY)                                                                 \
     for (int j0_ = 0; j0_ < (H).n; j0_ += 64) {                                                          \
@@ -1473,8 +1592,12 @@ __global__ __launch_bounds__(256) void k_tr_pfn_lin(PfnT p, float* __restrict__ 
     __shared__ float sp[4][2][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
-    float w[10][CPL];
-    pfn_load_weights<CPL>(p, lane, w);
+    PfnFold<CPL> fw;
+    {
+        float w[10][CPL];
+        pfn_load_weights<CPL>(p, lane, w);
+        pfn_fold<CPL>(w, fw);
+    }
     float s1[CPL], s2[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) s1[q] = s2[q] = 0.f;
@@ -1484,10 +1607,12 @@ __global__ __launch_bounds__(256) void k_tr_pfn_lin(PfnT p, float* __restrict__ 
         PillarHead h;
         pillar_head(p, gp, lane, bcur, h);
         pillar_record_store(p, gp, h, lane);
-        PFN_FOR_POINTS(p, h, lane, {
+        float K[CPL];
+        pfn_pillar_const<CPL>(fw, h.cx, h.cy, h.mx, h.my, h.mz, K);
+        PFN_FOR_POINTS2(p, h, lane, {
             (void)j;
             float y[CPL];
-            pfn_dense<CPL>(f, w, y);
+            pfn_y<CPL>(fw, pt, K, y);
 _Pragma("unroll")
             for (int q = 0; q < CPL; ++q) { s1[q] += y[q]; s2[q] = fmaf(y[q], y[q], s2[q]); }
         })
@@ -1509,8 +1634,12 @@ __global__ __launch_bounds__(256) void k_tr_pfn_max(PfnT p, const float* __restr
                                                     float* __restrict__ feat, int* __restrict__ arg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
-    float w[10][CPL];
-    pfn_load_weights<CPL>(p, lane, w);
+    PfnFold<CPL> fw;
+    {
+        float w[10][CPL];
+        pfn_load_weights<CPL>(p, lane, w);
+        pfn_fold<CPL>(w, fw);
+    }
     float sc[CPL], sh[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
@@ -1520,16 +1649,16 @@ __global__ __launch_bounds__(256) void k_tr_pfn_max(PfnT p, const float* __restr
         sh[q] = (c < C) ? beta[c] - stats[2 * c] * inv : 0.f;
     }
     const int total = p.pprefix[p.batch];
-    for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
-        PillarRec h;
-        pillar_record_load(p, gp, lane, h);
+    pfn_for_pillars(p, total, lane, wave, [](const PillarRec&) {}, []() {}, [&](const PillarRec& h) {
         float best[CPL];
         int bi[CPL];
 #pragma unroll
         for (int q = 0; q < CPL; ++q) { best[q] = -3.0e38f; bi[q] = -2; }
-        PFN_FOR_POINTS(p, h, lane, {
+        float K[CPL];
+        pfn_pillar_const<CPL>(fw, h.cx, h.cy, h.mx, h.my, h.mz, K);
+        PFN_FOR_POINTS2(p, h, lane, {
             float y[CPL];
-            pfn_dense<CPL>(f, w, y);
+            pfn_y<CPL>(fw, pt, K, y);
 _Pragma("unroll")
             for (int q = 0; q < CPL; ++q) {
                 const float v = fmaf(y[q], sc[q], sh[q]);
@@ -1545,7 +1674,7 @@ _Pragma("unroll")
             feat[(size_t)h.slot * C + c] = best[q];                              // rows of feat / arg: frame * max_voxels + pillar
             arg[(size_t)h.slot * C + c] = bi[q];
         }
-    }
+    });
 }
 
 // canvas[b][y][x][c] = sum over the z cells of the pillar features that map to (y, x) (tf.scatter_nd adds duplicates)
@@ -1577,36 +1706,57 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_reduce(PfnT p, const float* 
     __shared__ float sp[4][2][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
-    float w[10][CPL];
-    pfn_load_weights<CPL>(p, lane, w);
+    PfnFold<CPL> fw;
+    {
+        float w[10][CPL];
+        pfn_load_weights<CPL>(p, lane, w);
+        pfn_fold<CPL>(w, fw);
+    }
     float s1[CPL], s2[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) s1[q] = s2[q] = 0.f;
     const int total = p.pprefix[p.batch];
-    const int ncanvas = p.nx * p.ny;
-    for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
-        PillarRec h;
-        pillar_record_load(p, gp, lane, h);
-        const size_t crow = (size_t)(h.slot / p.max_voxels) * ncanvas + h.cellxy;        // canvas row of the pillar
+    int an[CPL], ac[CPL];                               // winning rows / canvas gradients of the next and the current pillar
+    float gn[CPL], gc[CPL];
+    auto red_prefetch = [&](const PillarRec& hn) {
+        const size_t crow = (size_t)hn.crow;                   // canvas row of the pillar
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = lane * CPL + q;
+            an[q] = (c < C) ? arg[(size_t)hn.slot * C + c] : -2;
+            gn[q] = (c < C) ? dcanvas[crow * C + c] : 0.f;
+        }
+    };
+    auto red_take = [&]() {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { ac[q] = an[q]; gc[q] = gn[q]; }
+    };
+    pfn_for_pillars(p, total, lane, wave, red_prefetch, red_take, [&](const PillarRec& h) {
+        float K[CPL];
+        pfn_pillar_const<CPL>(fw, h.cx, h.cy, h.mx, h.my, h.mz, K);
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = lane * CPL + q;
             if (c >= C) continue;
-            const int a = arg[(size_t)h.slot * C + c];
+            const int a = ac[q];
             if (a == -2) continue;
-            const float g = dcanvas[crow * C + c];
+            const float g = gc[q];
             float y = 0.f;
-            if (a >= 0) {
-                const float* pt = p.pts_sorted + (size_t)(h.row0 + a) * p.F;
-                float f[10];
-                pfn_features(p, pt[0], pt[1], pt[2], (p.F > 3) ? pt[3] : 0.f, h.mx, h.my, h.mz, h.cx, h.cy, f);
-#pragma unroll
-                for (int k = 0; k < 10; ++k) y = fmaf(f[k], w[k][q], y);
+            if (a >= 0) {      // the winning row's y: the same folded chain as the forward kernels (per-lane point)
+                const float* pr = p.pts_sorted + (size_t)(h.row0 + a) * p.F;
+                const PfnPt pt = pfn_point(p, pr[0], pr[1], pr[2], (p.F > 3) ? pr[3] : 0.f, h.cx, h.cy);
+                float v = K[q];
+                v = fmaf(pt.xl, fw.wsx[q], v);
+                v = fmaf(pt.yl, fw.wsy[q], v);
+                v = fmaf(pt.z, fw.wsz[q], v);
+                v = fmaf(pt.it, fw.wi[q], v);
+                v = fmaf(pt.nrm, fw.wn[q], v);
+                y = v;
             }
             const float yh = (y - stats[2 * c]) * stats[2 * c + 1];
             s1[q] += g; s2[q] = fmaf(g, yh, s2[q]);
         }
-    }
+    });
 #pragma unroll
     for (int q = 0; q < CPL; ++q) { sp[wave][0][lane * CPL + q] = s1[q]; sp[wave][1][lane * CPL + q] = s2[q]; }
     __syncthreads();
@@ -1625,8 +1775,13 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* _
     __shared__ float sp[4][10][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.C;
-    float w[10][CPL], dw[10][CPL];                          // (canonical feature order, as pfn_features)
-    pfn_load_weights<CPL>(p, lane, w);
+    float dw[10][CPL];                                      // (canonical feature order, as pfn_features)
+    PfnFold<CPL> fw;
+    {
+        float w[10][CPL];
+        pfn_load_weights<CPL>(p, lane, w);
+        pfn_fold<CPL>(w, fw);
+    }
 #pragma unroll
     for (int k = 0; k < 10; ++k)
 #pragma unroll
@@ -1644,31 +1799,59 @@ __global__ __launch_bounds__(256) void k_tr_pfn_bwd_apply(PfnT p, const float* _
         m2[q] = ok ? sums[C + c] / n_rows : 0.f;
     }
     const int total = p.pprefix[p.batch];
-    const int ncanvas = p.nx * p.ny;
-    for (int gp = (int)blockIdx.x * 4 + wave; gp < total; gp += (int)gridDim.x * 4) {
-        PillarRec h;
-        pillar_record_load(p, gp, lane, h);
-        const size_t crow = (size_t)(h.slot / p.max_voxels) * ncanvas + h.cellxy;
-        float g[CPL];
-        int a[CPL];
+    int an[CPL], a[CPL];                                // winning rows / canvas gradients of the next and the current pillar
+    float gn[CPL], g[CPL];
+    auto app_prefetch = [&](const PillarRec& hn) {
+        const size_t crow = (size_t)hn.crow;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const int c = lane * CPL + q;
-            a[q] = (c < C) ? arg[(size_t)h.slot * C + c] : -2;
-            g[q] = (c < C && a[q] >= 0) ? dcanvas[crow * C + c] : 0.f;
+            an[q] = (c < C) ? arg[(size_t)hn.slot * C + c] : -2;
+            gn[q] = (c < C) ? dcanvas[crow * C + c] : 0.f;        // (issued with the index load, masked in app_take)
         }
-        PFN_FOR_POINTS(p, h, lane, {
+    };
+    auto app_take = [&]() {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { a[q] = an[q]; g[q] = (an[q] >= 0) ? gn[q] : 0.f; }
+    };
+    pfn_for_pillars(p, total, lane, wave, app_prefetch, app_take, [&](const PillarRec& h) {
+        float K[CPL];
+        pfn_pillar_const<CPL>(fw, h.cx, h.cy, h.mx, h.my, h.mz, K);
+        float S0[CPL], Sx[CPL], Sy[CPL], Sz[CPL], Si[CPL], Sn[CPL];     // the pillar's sums of dy, x' dy, y' dy, z dy, i dy, |p| dy
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) S0[q] = Sx[q] = Sy[q] = Sz[q] = Si[q] = Sn[q] = 0.f;
+        PFN_FOR_POINTS2(p, h, lane, {
             float y[CPL];
-            pfn_dense<CPL>(f, w, y);
+            pfn_y<CPL>(fw, pt, K, y);
 _Pragma("unroll")
             for (int q = 0; q < CPL; ++q) {
                 const float yh = (y[q] - mean[q]) * inv[q];
                 const float dy = gi[q] * (((a[q] == j) ? g[q] : 0.f) - m1[q] - yh * m2[q]);
-_Pragma("unroll")
-                for (int k = 0; k < 10; ++k) dw[k][q] = fmaf(f[k], dy, dw[k][q]);
+                S0[q] += dy;
+                Sx[q] = fmaf(pt.xl, dy, Sx[q]);
+                Sy[q] = fmaf(pt.yl, dy, Sy[q]);
+                Sz[q] = fmaf(pt.z, dy, Sz[q]);
+                Si[q] = fmaf(pt.it, dy, Si[q]);
+                Sn[q] = fmaf(pt.nrm, dy, Sn[q]);
             }
         })
-    }
+        {   // canonical rows: 0 1 2 = x y z, 3 = intensity, 4 5 6 = xyz - mean, 7 8 = xy - centre, 9 = norm
+            const float dmx = h.mx - h.cx, dmy = h.my - h.cy;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                dw[0][q] += fmaf(h.cx, S0[q], Sx[q]);
+                dw[1][q] += fmaf(h.cy, S0[q], Sy[q]);
+                dw[2][q] += Sz[q];
+                dw[3][q] += Si[q];
+                dw[4][q] += fmaf(-dmx, S0[q], Sx[q]);
+                dw[5][q] += fmaf(-dmy, S0[q], Sy[q]);
+                dw[6][q] += fmaf(-h.mz, S0[q], Sz[q]);
+                dw[7][q] += Sx[q];
+                dw[8][q] += Sy[q];
+                dw[9][q] += Sn[q];
+            }
+        }
+    });
 #pragma unroll
     for (int k = 0; k < 10; ++k)
 #pragma unroll
@@ -1876,7 +2059,7 @@ __global__ void k_tr_pfn_rows(const int* __restrict__ npillars, int batch, int T
 
 // Persistent PFN grids: one resident round of workgroups (a quarter-filled second round costs a whole one).  Resident
 // 4-wave workgroups per CU follow the kernels' register budgets: CPL 1 / 2 / 4 -> lin 8 / 7 / 4, max 7 / 5 / 4,
-// bwd_reduce 8 / 6 / 4, bwd_apply 6 / 4 / 3.
+// bwd_reduce 8 / 6 / 4, bwd_apply 5 / 3 / 2.
 static int pfn_blocks(int per_cu) { return std::min(TR_NPART, per_cu * 256); }
 
 template <int CPL>
@@ -1893,7 +2076,8 @@ void pfn_forward(const TrainCtx& cx, const PfnT& p, const Lookup& L) {
 
 template <int CPL>
 void pfn_backward(const TrainCtx& cx, const PfnT& p, const Lookup& L, const float* dcanvas) {
-    const int nred = pfn_blocks(CPL == 4 ? 4 : 6), nblk = pfn_blocks(CPL == 4 ? 3 : 4);
+    // (register budgets with the pillar pipeline: bwd_reduce 54 / 79 / 115 VGPRs, bwd_apply 95 / 138 / 214)
+    const int nred = pfn_blocks(CPL == 4 ? 4 : 6), nblk = pfn_blocks(CPL == 4 ? 2 : (CPL == 2 ? 3 : 5));
     PP_LAUNCH("k_tr_pfn_bwd_reduce", (k_tr_pfn_bwd_reduce<CPL>), dim3(nred), dim3(256), 0, cx.stream, p,
               (const float*)cx.pfn_stats, (const int*)cx.pfn_arg, dcanvas, cx.part);
     col_reduce(cx, p.C, cx.pfn_sums, L.g("pfn/bn/beta"), L.g("pfn/bn/gamma"), cx.part, (long)2 * p.C, nred);
