@@ -50,7 +50,20 @@ struct pp_engine {
     // batch k); d_points / d_offsets point at the buffer the next pp_detect_async consumes
     float* d_points_buf[2] = {nullptr, nullptr};
     int* d_offsets_buf[2] = {nullptr, nullptr};
-    int in_buf = 0;                       // index of d_points / d_offsets
+    int in_buf = 0;                       // index of d_points / d_offsets (and of the voxeliser products: vox[])
+    // The voxeliser's products exist twice as well (round 4): pp_upload_points_async voxelises batch k+1 right behind
+    // its copy, on the copy stream, while batch k's PFN .. post-process read the other set -- the single-workgroup-
+    // per-frame voxeliser (36 us on 64 of 256 CUs at B = 64) is then off the pass's chain of dependent launches.
+    // The d_* members below always point at set in_buf.
+    struct VoxSet {
+        float* points_sorted = nullptr;
+        int *cellmap = nullptr, *pstart = nullptr, *pcell = nullptr, *npillars = nullptr, *nvalid = nullptr;
+        unsigned long long* occbits = nullptr;
+        bool occ_cleared = false;         // its k_cell_first cleared the occupancy bitmap (consumed by run_pfn)
+    } vox[2];
+    bool vox_ahead = false;               // the resident batch was voxelised at upload time (pp_detect_async skips it)
+    bool prevox_issued = false;           // a voxeliser launch is (or was) queued on the copy stream: a main-stream one waits for ev_up
+    int results_buf = 0;                  // set the last pp_detect_async read (pp_fetch_intermediates)
     hipStream_t copy_stream = nullptr;   // the device's shared upload stream (not owned by the handle)
     hipEvent_t ev_up = nullptr;           // recorded on the copy stream behind an asynchronous upload
     hipEvent_t ev_tgt = nullptr;          // ... behind the labels / regression targets of a training step
@@ -87,7 +100,7 @@ struct pp_engine {
     int* d_integ = nullptr;
     unsigned long long* d_occbits = nullptr;   // [B][ny][occ_words(nx)] occupancy bitmap of the sparse-canvas passes
     bool occbits_live = false;                 // this pass's PFN launch wrote it (the pillar-centric kernel)
-    bool occbits_cleared = false;              // ... after this pass's k_cell_first cleared it
+    bool ablate_vox_done = false;              // PP_ABLATE_STAGES bit 1 (timing experiments)
     uint8_t* d_mask = nullptr;
     float* d_anchors = nullptr;
     int* d_cells = nullptr;
@@ -149,7 +162,7 @@ struct pp_engine {
 
     int prof = 0;
     // pp_detect_async as one hipGraph launch (captured on first use per (batch, max points per frame))
-    struct GraphSlot { hipGraphExec_t exec = nullptr; int batch = -1, bucket = -1, buf = -1, zc = 0; unsigned long long used = 0; };
+    struct GraphSlot { hipGraphExec_t exec = nullptr; int batch = -1, bucket = -1, buf = -1, zc = 0, vox = 0; unsigned long long used = 0; };
     GraphSlot graphs[8];          // small LRU keyed by (batch, point-count bucket, input buffer)
     unsigned long long graph_tick = 0;
     int graph_state = 0;          // 0: try, -1: capture failed once (use plain launches)
@@ -161,6 +174,14 @@ struct pp_engine {
 
 namespace {
 
+// PP_CU_PARTITION=n (measurement switch, default 0 = off): n compute units of every XCD are reserved for the upload /
+// voxeliser stream, the handles' own streams get the other 32 - n, and the persistent grids are sized for those
+static int cu_partition() {
+    static int v = -1;
+    if (v < 0) { const char* s = getenv("PP_CU_PARTITION"); v = s ? atoi(s) : 0; if (v < 0 || v > 16) v = 0; }
+    return v;
+}
+
 // process-wide upload stream of a device (created on first use, lives as long as the process)
 hipStream_t device_copy_stream(int device) {
     static std::mutex mu;
@@ -169,7 +190,12 @@ hipStream_t device_copy_stream(int device) {
     auto it = streams.find(device);
     if (it != streams.end()) return it->second;
     hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    const int part = cu_partition();
+    if (part > 0) {   // experiment (PP_CU_PARTITION): the upload + voxeliser stream on `part` CUs of every XCD, the handles' on the rest
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 8 * part; ++i) mask[i >> 5] |= 1u << (i & 31);
+        if (hipExtStreamCreateWithCUMask(&s, 8, mask) != hipSuccess) return nullptr;
+    } else if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
     streams[device] = s;
     return s;
 }
@@ -380,13 +406,13 @@ static bool f16_pair_range_ok(const std::vector<float>& wt) {
 
 // canvas -> host (debug taps).  With the sparse canvas the cells without a pillar were never written: they are
 // zeroed here from the cell map, so the caller sees the dense pseudo-image of the reference.
-static int fetch_canvas(pp_engine* e, float* canvas, int batch) {
+static int fetch_canvas(pp_engine* e, float* canvas, int batch, int set) {
     const size_t plane = (size_t)e->ny * e->nx;
     HIPCHK(e, hipMemcpyAsync(canvas, e->d_canvas, (size_t)batch * plane * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (!e->sparse_canvas) return PP_OK;
     std::vector<int> cm((size_t)batch * e->nz * plane);
-    HIPCHK(e, hipMemcpy(cm.data(), e->d_cellmap, cm.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(cm.data(), e->vox[set].cellmap, cm.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int b = 0; b < batch; ++b)
         for (size_t c = 0; c < plane; ++c) {
             bool occ = false;
@@ -396,32 +422,45 @@ static int fetch_canvas(pp_engine* e, float* canvas, int batch) {
     return PP_OK;
 }
 
+// the voxeliser products the d_* members name: set i (follows in_buf)
+static void use_vox_set(pp_engine* e, int i) {
+    const pp_engine::VoxSet& v = e->vox[i];
+    e->d_points_sorted = v.points_sorted; e->d_cellmap = v.cellmap; e->d_pstart = v.pstart; e->d_pcell = v.pcell;
+    e->d_npillars = v.npillars; e->d_nvalid = v.nvalid; e->d_occbits = v.occbits;
+}
+
 // ---- stage pipelines (all enqueue on e->stream) ----
 const unsigned* sorted_idx(pp_engine* e);
-int run_voxelize(pp_engine* e, int batch, int max_n) {
+int run_voxelize(pp_engine* e, int batch, int max_n, hipStream_t vs = nullptr) {
+    if (vs == nullptr) {
+        vs = e->stream;
+        // the voxeliser's scratch (cells, keys, indices) exists once: a launch here must not overtake one that
+        // pp_upload_points_async queued on the copy stream
+        if (e->prevox_issued) { HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_up, 0)); e->prevox_issued = false; }
+    }
     const bool lds_first = voxel_first_in_lds(max_n, e->ncell, e->cfg.max_voxels);
     int* d_first = lds_first ? nullptr : e->d_first;
     if (!lds_first) {
         ProfScope ps(e, "memset_first", true);
-        HIPCHK(e, hipMemsetAsync(e->d_first, 0x7f, (size_t)batch * e->ncell * sizeof(int), e->stream));
+        HIPCHK(e, hipMemsetAsync(e->d_first, 0x7f, (size_t)batch * e->ncell * sizeof(int), vs));
     }
     {
         ProfScope ps(e, "k_cell_first");   // also clears the cell map
         launch_cell_first(e->d_points, e->d_offsets, batch, max_n, e->F, e->geom, e->d_cell, d_first, e->d_cellmap,
-                          e->zc ? e->d_feed[e->in_buf] : nullptr, e->d_points, e->d_offsets, e->stream,
+                          e->zc ? e->d_feed[e->in_buf] : nullptr, e->d_points, e->d_offsets, vs,
                           e->sparse_canvas ? e->d_occbits : nullptr, e->ny * occ_words(e->nx));
-        e->occbits_cleared = e->sparse_canvas;
+        e->vox[e->in_buf].occ_cleared = e->sparse_canvas;
     }
     {
         ProfScope ps(e, "k_voxel_frame");
         launch_voxel_frame(e->d_offsets, e->d_cell, d_first, e->d_cellmap, e->d_keyA, e->d_idxA, e->d_keyB,
                            e->d_idxB, e->d_pstart, e->d_pcell, e->d_npillars, e->d_nvalid, batch, max_n, e->ncell,
-                           e->cfg.max_voxels, e->stream);
+                           e->cfg.max_voxels, vs);
     }
     {
         ProfScope ps(e, "k_sort_points");
         launch_sort_points(e->d_points, e->d_offsets, sorted_idx(e), e->d_nvalid, batch, max_n, e->F,
-                           e->d_points_sorted, e->stream);
+                           e->d_points_sorted, vs);
     }
     HIPCHK(e, hipGetLastError());
     return PP_OK;
@@ -460,10 +499,10 @@ int run_pfn(pp_engine* e, int batch, bool padded, float* feat_out, bool with_mas
     p.with_distance = e->with_dist ? 1 : 0;
     // the bitmap is only as good as its clearing: the fused path's k_cell_first does it (run_voxelize); the stage entry
     // points build the cell map from the caller's coordinates and keep the cell-map lookups
-    p.occbits = (e->sparse_canvas && !padded && e->occbits_cleared) ? e->d_occbits : nullptr;
+    p.occbits = (e->sparse_canvas && !padded && e->vox[e->in_buf].occ_cleared) ? e->d_occbits : nullptr;
     e->occbits_live = p.occbits != nullptr && pfn_writes_occbits(p, padded);
     if (!e->occbits_live) p.occbits = nullptr;
-    e->occbits_cleared = false;
+    e->vox[e->in_buf].occ_cleared = false;
     e->mask_in_pfn = false;
     if (with_mask && batch <= anchor_mask_in_pfn_max_batch() && pfn_can_carry_anchor_mask(p, padded)) {
         // the anchor mask (needs the cell map only, read by the post-process only) rides in this launch
@@ -507,7 +546,7 @@ int run_backbone(pp_engine* e, int batch) {
     for (size_t i = 0; i < e->layers.size(); ++i) {
         LayerDesc L = e->layers[i];
         // sparse first layer: the occupancy bitmap when this pass's PFN launch left one, else the cell map
-        if (i == 0 && L.d_occ != nullptr) L.d_occbits = e->occbits_live ? e->d_occbits : nullptr;
+        if (i == 0 && L.d_occ != nullptr) { L.d_occ = e->d_cellmap; L.d_occbits = e->occbits_live ? e->d_occbits : nullptr; }
         ProfScope ps(e, e->layer_tags[i].c_str());
         int st = launch_layer(L, batch, e->d_head, e->stream);
         if (st) return fail(e, st, "layer %s: unsupported shape (cin=%d cout=%d)", L.name, L.cin, L.cout);
@@ -569,6 +608,8 @@ int set_offsets(pp_engine* e, const int32_t* off, int batch, hipStream_t stream)
     e->in_buf = nb;
     e->d_points = e->d_points_buf[nb];
     e->d_offsets = e->d_offsets_buf[nb];
+    use_vox_set(e, nb);
+    e->vox_ahead = false;
     HIPCHK(e, hipStreamWaitEvent(stream, e->ev_read[nb], 0));   // (a no-op on the main stream, which is ordered anyway)
     HIPCHK(e, hipMemcpyAsync(e->d_offsets, ring, (batch + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(e, hipEventRecord(e->off_ev[slot], stream));
@@ -647,7 +688,17 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
     e->cfg = *cfg;
     e->device = device;
     hipError_t st = hipSetDevice(device);
-    if (st == hipSuccess) st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (st == hipSuccess) {
+        const int part = cu_partition();
+        if (part > 0) {
+            uint32_t mask[8];
+            for (int w = 0; w < 8; ++w) mask[w] = 0xffffffffu;
+            for (int i = 0; i < 8 * part; ++i) mask[i >> 5] &= ~(1u << (i & 31));
+            st = hipExtStreamCreateWithCUMask(&e->stream, 8, mask);
+        } else {
+            st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        }
+    }
     if (st != hipSuccess) {
         fail(nullptr, PP_ERR_HIP, "pp_create: %s", hipGetErrorString(st));
         delete e;
@@ -656,7 +707,7 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
-            g_num_cus = ncu;
+            g_num_cus = ncu - 8 * cu_partition();
     }
     for (int j = 0; j < 3; ++j) {
         e->geom.lo[j] = cfg->pc_range[j];
@@ -771,6 +822,19 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
             A1(dalloc(q, &e->d_cls, (size_t)e->B * HW * e->napl * e->ncls));
             A1(dalloc(q, &e->d_integ, (size_t)e->B * e->ny * e->nx));
             A1(dalloc(q, &e->d_occbits, (size_t)e->B * e->ny * occ_words(e->nx)));
+            {   // voxeliser products, set 0 = the buffers above, set 1 = a second copy (see pp_engine::vox)
+                pp_engine::VoxSet& v0 = e->vox[0];
+                v0.points_sorted = e->d_points_sorted; v0.cellmap = e->d_cellmap; v0.pstart = e->d_pstart; v0.pcell = e->d_pcell;
+                v0.npillars = e->d_npillars; v0.nvalid = e->d_nvalid; v0.occbits = e->d_occbits;
+                pp_engine::VoxSet& v1 = e->vox[1];
+                A1(dalloc(q, &v1.points_sorted, BN * e->F));
+                A1(dalloc(q, &v1.cellmap, (size_t)e->B * e->ncell));
+                A1(dalloc(q, &v1.pstart, (size_t)e->B * (cfg->max_voxels + 1)));
+                A1(dalloc(q, &v1.pcell, BMV));
+                A1(dalloc(q, &v1.npillars, (size_t)e->B));
+                A1(dalloc(q, &v1.nvalid, (size_t)e->B));
+                A1(dalloc(q, &v1.occbits, (size_t)e->B * e->ny * occ_words(e->nx)));
+            }
             A1(dalloc(q, &e->d_mask, (size_t)e->B * e->A));
             A1(dalloc(q, &e->d_anchors, (size_t)e->A * 7));
             A1(dalloc(q, &e->d_cells, (size_t)e->A * 4));
@@ -1097,6 +1161,8 @@ static int feed_zero_copy(pp_engine* e, const float* points_pinned, const int32_
     e->in_buf = nb;
     e->d_points = e->d_points_buf[nb];
     e->d_offsets = e->d_offsets_buf[nb];
+    use_vox_set(e, nb);
+    e->vox_ahead = false;
     e->cur_batch = batch;
     e->cur_max_n = max_n;
     e->up_pending = false;
@@ -1119,6 +1185,16 @@ int pp_upload_points_async(pp_handle e, const float* points_pinned, const int32_
     st = set_offsets(e, frame_offsets, batch, e->copy_stream); if (st) return st;
     const size_t n = (size_t)frame_offsets[batch];
     if (n) HIPCHK(e, hipMemcpyAsync(e->d_points, points_pinned, n * e->F * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
+    // Voxelise right here, behind the copy and beside the pass in flight (PP_PREVOX=0: inside pp_detect_async as before).
+    // Not while per-launch times are collected (their events belong to the main stream's pass) and not on a handle that
+    // trains (pp_train_step voxelises inside its own graphs).
+    static int prevox = -1;
+    if (prevox < 0) { const char* s_ = getenv("PP_PREVOX"); prevox = (s_ && s_[0] == '0') ? 0 : 1; }
+    if (prevox && e->prof <= 0 && e->train == nullptr) {
+        if ((st = run_voxelize(e, batch, e->cur_max_n, e->copy_stream))) return st;
+        e->vox_ahead = true;
+        e->prevox_issued = true;
+    }
     HIPCHK(e, hipEventRecord(e->ev_up, e->copy_stream));
     e->up_pending = true;
     return PP_OK;
@@ -1209,7 +1285,15 @@ static int graph_bucket(const pp_engine* e, int max_n) {
 // the whole fused pipeline of one batch, enqueued on e->stream (plain launches or under stream capture)
 static int enqueue_detect(pp_engine* e, int B, int max_n) {
     int st;
-    if ((st = run_voxelize(e, B, max_n))) return st;
+    // PP_ABLATE_STAGES (timing experiments only, WRONG results): bit 1 = the single-workgroup-per-frame voxeliser
+    // kernel is left out after the handle's first pass (later passes reuse its products), bit 2 = no post-process.
+    // What the step gains without them is what splitting them over more workgroups could gain at most.
+    static int abl = -1;
+    if (abl < 0) { const char* s_ = getenv("PP_ABLATE_STAGES"); abl = s_ ? atoi(s_) : 0; }
+    if (!e->vox_ahead && !((abl & 1) && e->ablate_vox_done)) {
+        if ((st = run_voxelize(e, B, max_n))) return st;
+        e->ablate_vox_done = true;
+    }
     if ((st = run_pfn(e, B, false, nullptr, true))) return st;
     if (!e->mask_in_pfn && (st = run_anchor_mask(e, B))) return st;
     if ((st = run_backbone(e, B))) return st;
@@ -1217,7 +1301,7 @@ static int enqueue_detect(pp_engine* e, int B, int max_n) {
     // the two device-to-host copy nodes of rounds 1-3 instead)
     static int post_copy = -1;
     if (post_copy < 0) { const char* s = getenv("PP_POST_COPY"); post_copy = (s && s[0] == '1') ? 1 : 0; }
-    if ((st = run_post(e, B, post_copy == 0))) return st;
+    if (!(abl & 2) && (st = run_post(e, B, post_copy == 0))) return st;
     if (post_copy) {
         HIPCHK(e, hipMemcpyAsync(e->h_dets, e->d_dets, (size_t)B * e->cfg.nms_post_max_size * sizeof(pp_detection), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(e, hipMemcpyAsync(e->h_ndets, e->d_ndets, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -1242,9 +1326,10 @@ int pp_detect_async(pp_handle e) {
     (void)hipSetDevice(e->device);
     const int B = e->cur_batch;
     prof_reset(e);
-    if (e->up_pending) {   // the frames were uploaded on the copy stream
-        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_up, 0));
+    if (e->up_pending || e->prevox_issued) {   // the frames were uploaded (and voxelised) on the copy stream
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_up, 0));     // (outside any capture: the event is not part of the graph)
         e->up_pending = false;
+        e->prevox_issued = false;
     }
     // ~35 launches per batch replay as ONE graph launch: every kernel argument is a device pointer or a
     // per-(batch, max points) constant, so the captured graph is reusable until either changes (profiling
@@ -1254,7 +1339,8 @@ int pp_detect_async(pp_handle e) {
         pp_engine::GraphSlot* slot = nullptr;
         pp_engine::GraphSlot* lru = &e->graphs[0];
         for (auto& g : e->graphs) {
-            if (g.exec && g.batch == B && g.bucket == bucket && g.buf == e->in_buf && g.zc == (e->zc ? 1 : 0)) slot = &g;
+            if (g.exec && g.batch == B && g.bucket == bucket && g.buf == e->in_buf && g.zc == (e->zc ? 1 : 0) &&
+                g.vox == (e->vox_ahead ? 1 : 0)) slot = &g;
             if (g.used < lru->used) lru = &g;
         }
         if (slot == nullptr) {
@@ -1274,6 +1360,7 @@ int pp_detect_async(pp_handle e) {
                 slot->bucket = bucket;
                 slot->buf = e->in_buf;
                 slot->zc = e->zc ? 1 : 0;
+                slot->vox = e->vox_ahead ? 1 : 0;
             } else {
                 slot->exec = nullptr;
                 e->graph_state = -1;           // fall back to plain launches for the life of the handle
@@ -1286,6 +1373,7 @@ int pp_detect_async(pp_handle e) {
             HIPCHK(e, hipGraphLaunch(slot->exec, e->stream));
             HIPCHK(e, hipEventRecord(e->ev_read[e->in_buf], e->stream));
             e->results_batch = B;
+            e->results_buf = e->in_buf;
             return PP_OK;
         }
     }
@@ -1293,6 +1381,7 @@ int pp_detect_async(pp_handle e) {
     if (st == PP_OK) {
         HIPCHK(e, hipEventRecord(e->ev_read[e->in_buf], e->stream));
         e->results_batch = B;
+        e->results_buf = e->in_buf;
     }
     return st;
 }
@@ -1450,7 +1539,7 @@ int pp_forward_voxels(pp_handle e, const float* voxels, const int32_t* num_point
     if (pillar_features && P)
         HIPCHK(e, hipMemcpyAsync(pillar_features, e->d_feat, (size_t)P * e->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (canvas && (st = fetch_canvas(e, canvas, batch))) return st;
+    if (canvas && (st = fetch_canvas(e, canvas, batch, e->in_buf))) return st;
     stage_call_done(e);
     return PP_OK;
 }
@@ -1492,12 +1581,13 @@ int pp_fetch_intermediates(pp_handle e, int32_t* n_pillars, int32_t* coors, int3
     HIPCHK(e, hipStreamSynchronize(e->stream));
     const int MV = e->cfg.max_voxels;
     std::vector<int> np(B);
-    HIPCHK(e, hipMemcpy(np.data(), e->d_npillars, B * sizeof(int), hipMemcpyDeviceToHost));
+    const pp_engine::VoxSet& vs = e->vox[e->results_buf];      // the set that pass read (a later upload has flipped the d_* members)
+    HIPCHK(e, hipMemcpy(np.data(), vs.npillars, B * sizeof(int), hipMemcpyDeviceToHost));
     if (n_pillars) memcpy(n_pillars, np.data(), B * sizeof(int));
     if (coors || num_points) {
         std::vector<int> pcell((size_t)B * MV), pstart((size_t)B * (MV + 1));
-        HIPCHK(e, hipMemcpy(pcell.data(), e->d_pcell, pcell.size() * sizeof(int), hipMemcpyDeviceToHost));
-        HIPCHK(e, hipMemcpy(pstart.data(), e->d_pstart, pstart.size() * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(pcell.data(), vs.pcell, pcell.size() * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(e, hipMemcpy(pstart.data(), vs.pstart, pstart.size() * sizeof(int), hipMemcpyDeviceToHost));
         for (int b = 0; b < B; ++b)
             for (int p = 0; p < np[b]; ++p) {
                 const size_t r = (size_t)b * MV + p;
@@ -1518,7 +1608,7 @@ int pp_fetch_intermediates(pp_handle e, int32_t* n_pillars, int32_t* coors, int3
         int st = fetch_heads(e, B, box_preds, cls_preds, dir_cls_preds);
         if (st) return st;
     }
-    if (canvas) { int stc = fetch_canvas(e, canvas, B); if (stc) return stc; }
+    if (canvas) { int stc = fetch_canvas(e, canvas, B, e->results_buf); if (stc) return stc; }
     return PP_OK;
 }
 
@@ -1880,9 +1970,10 @@ int pp_train_step_async(pp_handle e, const float* params_dev, float* grads_dev, 
     (void)hipSetDevice(e->device);
     int st = train_state(e); if (st) return st;
     if ((st = train_buffers(e))) return st;
-    if (e->up_pending) {
+    if (e->up_pending || e->prevox_issued) {   // (prevox_issued: the handle served pp_detect_async passes before it trained)
         HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_up, 0));
         e->up_pending = false;
+        e->prevox_issued = false;
     }
     prof_reset(e);
     // labels and regression targets travel on the copy stream (behind the points, if their upload is still queued
