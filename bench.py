@@ -383,7 +383,7 @@ def cfgk_leg(pp, local_rank, steps=12, only_inflight=None):
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_cfgk.json")))
         if files:
             doc = json.load(open(files[-1]))
-            ent = doc["kernels"].get(dom)
+            ent = doc["kernels"].get(dom) or doc["kernels"].get(dom[:-1] + ",0>")   # (the symbol gained a sixth template parameter: TR = 0)
             src = {"file": os.path.basename(files[-1]), "git_head": doc.get("git_head"), "csrc_sha16": doc.get("csrc_sha16")}
             if ent is not None and doc.get("csrc_sha16") == csrc_sha16():
                 out["roofline"]["traffic"] = ent.get("hbm_bytes_per_launch")
@@ -681,7 +681,7 @@ def main():
             if "frac_of_hbm_roof" in ro else ro["frac"]
         roofline["avg_launch_ms_overlapped"] = ro["avg_launch_ms"]
     roofline["timing"] = ("start/stop HIP events carried by each launch (hipExtLaunchKernelGGL), one batch in flight; "
-                          "compare with AverageNs of profiles/r03_inflight1_kernel_stats.csv")
+                          "compare with AverageNs of profiles/r04_inflight1_kernel_stats.csv")
     # HBM traffic and matrix-pipe occupancy of the dominant kernel come from the committed counter passes
     # (rocprofv3 cannot run inside this process), per launch like `achieved`.  A pass is only quoted while the kernel
     # sources are the ones it ran on (sha of csrc/ recorded by the pass): otherwise null + "stale".
@@ -694,7 +694,7 @@ def main():
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
             if files:
                 doc = json.load(open(files[-1]))
-                ent = doc["kernels"].get(dominant)
+                ent = doc["kernels"].get(dominant) or doc["kernels"].get(dominant[:-1] + ",0>")   # (sixth template parameter: TR = 0)
                 src = {"file": os.path.basename(files[-1]), "git_head": doc.get("git_head"), "csrc_sha16": doc.get("csrc_sha16")}
                 if ent is not None and doc.get("csrc_sha16") == csrc_sha:
                     roofline[key] = ent.get(field)
