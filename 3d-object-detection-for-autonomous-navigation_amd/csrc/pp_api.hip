@@ -1895,7 +1895,11 @@ int train_buffers(pp_engine* e) {
     A1(dalloc(e, &cx.pw16, (size_t)std::max<long>(pw16_words, 8)));
     // split-K partial tiles + the regions of the step's deferred reductions (every weight gradient keeps its
     // partials until the end of the step): 64 MB at the reference's batch, 16 MB more per frame beyond 4
-    cx.gemm_part_floats = std::max<long>(16l << 20, (long)B * (4l << 20));
+    // (round 4: capped -- the deferred regions are bounded by the SHAPES, not the batch: a weight-gradient product keeps at
+    // most ~1 024 partial tiles of 64 x 64 floats, a depthwise layer 512 rows of 11 * cin, about two dozen of each per
+    // step; an engine created for 512 frames used to take 8.6 GB here.  Past the cap the products split less and the
+    // depthwise backward falls back to the shared scratch, train.hip)
+    cx.gemm_part_floats = std::min<long>(std::max<long>(16l << 20, (long)B * (4l << 20)), 192l << 20);
     A1(dalloc(e, &cx.gemm_part, (size_t)cx.gemm_part_floats));
     if (st == PP_OK) st = ensure_loss_buffers(e);
     if (st == PP_OK) t->buffers = true;

@@ -2329,13 +2329,20 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
                 // at most one resident round of workgroups (179 VGPRs with the nine window loads in flight: two per CU);
                 // 1 280 workgroups on 1 024 slots ran a quarter-filled second round
                 const int nblk = std::min(TR_NPART, 512);
-                if (g_arena_used + (long)nblk * n > cx.gemm_part_floats) return PP_ERR_UNSUPPORTED;
-                float* region = cx.gemm_part + g_arena_used;
+                // (arena exhausted: the partial rows go to the shared scratch and the kernel-gradient rows are added at
+                // once, as in the k_tr_dw_bwd_w branch below; the two sum rows are read by the next col_reduce before
+                // anything else writes the scratch)
+                const bool room = g_arena_used + (long)nblk * n <= cx.gemm_part_floats;
+                float* region = room ? cx.gemm_part + g_arena_used : cx.part;
                 PP_LAUNCH("k_tr_dw_bwd", k_tr_dw_bwd, dim3(nblk), dim3(256), 0, cx.stream, (const float*)cx.dD,
                           L.p(pre + "/depthwise_kernel"), (const float*)pb.Z, (const float4*)pb.coef, pb.dA, region, B, l.in_h,
                           l.in_w, l.cin);
-                g_jobs.push_back(ReduceJob{region, L.g(pre + "/depthwise_kernel"), (long)9 * l.cin, n, 0L, nblk, 0, 0, 1.0f});
-                g_arena_used += ((long)nblk * n + 63) / 64 * 64;
+                if (room) {
+                    g_jobs.push_back(ReduceJob{region, L.g(pre + "/depthwise_kernel"), (long)9 * l.cin, n, 0L, nblk, 0, 0, 1.0f});
+                    g_arena_used += ((long)nblk * n + 63) / 64 * 64;
+                } else {
+                    tr_reduce(cx.stream, (const float*)region, nblk, (long)9 * l.cin, n, L.g(pre + "/depthwise_kernel"), 0L, 0, 0, 1.0f);
+                }
                 sums_part = region + (long)9 * l.cin;
                 sums_pstride = n;
                 sums_nparts = nblk;
