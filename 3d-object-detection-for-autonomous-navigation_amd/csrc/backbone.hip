@@ -792,10 +792,15 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float inv_d, int& q, i
 template <int NT, int S, int WPS, int PREC, int OCC = 0, int TR = 0>
 __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     static_assert(TR == 0 || (PREC == 1 && OCC == 0), "training forward: split-precision, dense input");
-    constexpr int NTAP = TR ? 11 : 9;                // tap vectors per channel group in LDS (TR: + sc, sh)
+    // TR 2: the same launch WITHOUT the depthwise -- a plain product rows x cin -> rows x n_total of the training forward
+    // (transposed convolutions as GEMMs over their input pixels, the heads): the "window" is the pixel pair itself, the
+    // A tile is staged unchanged, epilogue and statistics as TR 1 (+ bias when given).  Rows past M read as zeros
+    // (out-of-range buffer offsets), so they add nothing to the statistics.
+    constexpr bool PW = TR == 2;
+    constexpr int NTAP = (TR == 1) ? 11 : 9;         // tap vectors per channel group in LDS (TR 1: + sc, sh)
     constexpr int KCH = 16, LSTR = KCH + 4, G = 4;
     constexpr int WW = S + 3;                        // input window width of 2 adjacent output pixels
-    constexpr int NLD = 3 * WW;
+    constexpr int NLD = PW ? 2 : 3 * WW;
     constexpr int SAW = 32 * LSTR;                   // one wave-private A buffer (floats)
     // weight tile in LDS: PREC 0 [NT][16 + 4] floats; PREC 1 [3 pieces][NT][16 bf16 = 8 floats], the two
     // 16-byte halves of a row swapped on odd groups of 8 rows (conflict-free ds_read_b128 without padding)
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     constexpr int NTILES = NT / 32;
     constexpr int KQ = KCH / 8;
     // (TR: + the workgroup's running column sums / sums of squares, one [2][NT] row per wave)
-    __shared__ __attribute__((aligned(16))) float smem[8 * SAW + 2 * SB + NTAP * 256 + (TR ? 8 * NT : 0)];
+    __shared__ __attribute__((aligned(16))) float smem[8 * SAW + 2 * SB + (PW ? 0 : NTAP * 256) + (TR ? 8 * NT : 0)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.dbg & 128) return;   // tuning aid: launch + dispatch cost only
 #ifdef PP_KERNEL_STAMPS   // diagnostic build: wall-clock phase stamps of every workgroup (wave 0)
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     float* const sAw = smem + wave * 2 * SAW;
     float* const sB = smem + 8 * SAW;
     float* const sDW = smem + 8 * SAW + 2 * SB;
-    [[maybe_unused]] float* const sST = smem + 8 * SAW + 2 * SB + NTAP * 256;
+    [[maybe_unused]] float* const sST = smem + 8 * SAW + 2 * SB + (PW ? 0 : NTAP * 256);
 
     // ---- this workgroup's tiles: XCD x (= blockIdx.x & 7, the dispatch order) owns the contiguous tile
     // range [x * ntiles / 8, (x + 1) * ntiles / 8); its workgroups walk that range together, so the halo
@@ -832,7 +837,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     const int first = tbase + gl;
     const int n0 = blockIdx.y * NT;
     if (first >= tend) {                               // uniform for the workgroup
-        if (TR && tid < 2 * NT)                        // its (all-zero) row of the statistics partials
+        if (TR && a.tr_stat != nullptr && tid < 2 * NT)   // its (all-zero) row of the statistics partials
             a.tr_stat[((size_t)blockIdx.x * 2 + tid / NT) * a.n_total + n0 + tid % NT] = 0.f;
         return;
     }
@@ -848,7 +853,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
 
     // ---- staging role: lane (q, c4) owns output pixels pw + 2q, +1 and channels 4*c4..+3 of a chunk ----
     const int c4 = lane & 3, q = lane >> 2;
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - PP_ZPAD_FLOATS * 4);
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(reinterpret_cast<const char*>(a.in) - (PW ? 0 : PP_ZPAD_FLOATS * 4));
     const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(PREC == 0 ? (const void*)a.wt : (const void*)a.wt16);
     const int hw = a.px_h * a.px_w;
     const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)a.px_w;
@@ -868,6 +873,10 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
         const bool pvalid_ = pix0_ < a.M;                                                                \
         if (TR) doff = pvalid_ ? (unsigned)pix0_ * (unsigned)cin4 + (unsigned)(c4 * 16) : 0x80000000u;  /* M even */ \
         const int pc_ = pvalid_ ? pix0_ : 0;                                                             \
+        if (PW) {   /* the pixel pair's own rows (row stride cin floats); a pair past the end reads zeros */ \
+            aoff[0] = pvalid_ ? (unsigned)pc_ * (unsigned)cin4 + (unsigned)(c4 * 16) : 0x80000000u;      \
+            aoff[NLD - 1] = pvalid_ ? aoff[0] + (unsigned)cin4 : 0x80000000u;                            \
+        } else {                                                                                         \
         int b_, rem_, y_, x0_;                                                                           \
         fast_divmod(pc_, hw, inv_hw, b_, rem_);        /* pixel counts < 2^24 (checked by the launcher) */ \
         fast_divmod(rem_, a.px_w, inv_w, y_, x0_);                                                       \
@@ -916,6 +925,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
                 }                                                                                        \
             }                                                                                            \
             aoff[e] = (ok_ ? rowoff_[dy_] + coloff_[dx_] : 0u) + (unsigned)(c4 * 16);                    \
+        }                                                                                                \
         }                                                                                                \
     }
     // weight staging items (16 bytes each): global byte offset and LDS float offset, fixed for the K loop
@@ -970,7 +980,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     // Staged AFTER the first window loads have been issued: the two memory round trips of the prologue overlap
     {
         const int ngrp = cin / 4;
-        for (int e = tid; e < 9 * ngrp; e += 256) {
+        if (!PW) for (int e = tid; e < 9 * ngrp; e += 256) {
             const int t = e / ngrp, g4 = e - t * ngrp;
             reinterpret_cast<float4*>(sDW)[g4 * NTAP + t] = reinterpret_cast<const float4*>(a.dw)[e];
         }
@@ -992,7 +1002,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     const int h = lane >> 5, r32 = lane & 31;
     float bias_r[NTILES];   // loaded once: a global load inside the epilogue would sit on its critical path
 #pragma unroll
-    for (int n = 0; n < NTILES; ++n) bias_r[n] = TR ? 0.f : a.bias[n0 + n * 32 + r32];
+    for (int n = 0; n < NTILES; ++n) bias_r[n] = (TR && a.bias == nullptr) ? 0.f : a.bias[n0 + n * 32 + r32];
     __syncthreads();   // depthwise taps visible
     U_STAMP(1)
 
@@ -1041,12 +1051,13 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
                 RIN[e].z = fmaxf(fmaf(RIN[e].z, sc_.z, sh_.z), 0.f); RIN[e].w = fmaxf(fmaf(RIN[e].w, sc_.w, sh_.w), 0.f);  \
             }                                                                                            \
         }                                                                                                \
-        if (!(dbg & 2)) {                                                                                \
+        if (PW) { o0 = RIN[0]; o1 = RIN[NLD - 1]; }                                                      \
+        if (!PW && !(dbg & 2)) {                                                                         \
             const float* tw = twp;                                                                       \
             _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                             \
                 _Pragma("unroll") for (int dx = 0; dx < 3; ++dx) {                                       \
                     const float4 w4 = *reinterpret_cast<const float4*>(tw + (dy * 3 + dx) * 4);          \
-                    const float4 v0 = RIN[dy * WW + dx], v1 = RIN[dy * WW + S + dx];                     \
+                    const float4 v0 = RIN[PW ? 0 : dy * WW + dx], v1 = RIN[PW ? 0 : dy * WW + S + dx];   \
                     o0.x = fmaf(v0.x, w4.x, o0.x); o0.y = fmaf(v0.y, w4.y, o0.y);                        \
                     o0.z = fmaf(v0.z, w4.z, o0.z); o0.w = fmaf(v0.w, w4.w, o0.w);                        \
                     o1.x = fmaf(v1.x, w4.x, o1.x); o1.y = fmaf(v1.y, w4.y, o1.y);                        \
@@ -1181,7 +1192,7 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     U_MFMA(1)
     ++mm_kc;
     U_EPILOGUE()
-    if (TR) {   // one statistics row per workgroup: [gridDim.x][2][n_total]; the four waves' sums added in a fixed order
+    if (TR && a.tr_stat != nullptr) {   // one statistics row per workgroup: [gridDim.x][2][n_total]; the four waves' sums added in a fixed order
         __syncthreads();                               // every wave's sums are in its row
         const float* red = sST;                        // [4 waves][2][NT]
         if (tid < 2 * NT) {
@@ -1273,6 +1284,40 @@ int launch_sep_train(const SepTrainArgs& t, hipStream_t s) {
         else PP_LAUNCH(tg, (k_sep_u<32, 2, 3, 1, 0, 1>), grid, dim3(256), 0, s, a, ntiles);
     }
     return gx;          // one statistics row per workgroup of a channel column
+#endif
+}
+
+// Training-mode forward of a plain product rows x K -> rows x N (a transposed convolution as a GEMM over its input
+// pixels, the heads): k_sep_u<..., TR = 2> -- no depthwise, the rest as launch_sep_train.  `in` needs no header.
+// Returns the statistics rows written (t.stat != NULL) or 1, 0 when the shape is not one the kernel takes.
+int launch_rows_train(const RowsTrainArgs& t, hipStream_t s) {
+#if PP_SPLIT_MODE != 1
+    (void)t; (void)s;
+    return 0;
+#else
+    const long long M = t.rows;
+    if (t.K % KC != 0 || t.N % 32 != 0 || M % 2 != 0 || M >= (1 << 24) || M * t.K * 4 >= (1ll << 31) - 4096 || t.ld_out % 4 != 0)
+        return 0;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = t.in; a.wt16 = t.wt16; a.n_total = t.N; a.out = t.out; a.bias = t.bias;
+    a.M = (int)M; a.in_h = 1; a.in_w = (int)M; a.cin = t.K; a.px_h = 1; a.px_w = (int)M;
+    a.stride = 1; a.ld_out = t.ld_out; a.co_off = 0; a.cout = t.N;
+    a.tr_stat = t.stat;
+    const int ntiles = (a.M + 127) / 128;
+    const int nt = (t.N % 128 == 0) ? 128 : (t.N % 64 == 0 ? 64 : 32);
+    const int ny = t.N / nt;
+    const int wpb = 3;          // (no depthwise: 159 / 105 / 76 VGPRs -- three workgroups per CU for every tile width)
+    int slots = (g_num_cus * wpb) / ny;
+    if (slots < 8) slots = 8;
+    int gx = ntiles < slots ? ntiles : slots;
+    gx = (gx + 7) & ~7;
+    const dim3 grid((unsigned)gx, ny);
+    const char* tg = t.tag ? t.tag : "k_sep_u_tr";
+    if (nt == 128) PP_LAUNCH(tg, (k_sep_u<128, 1, 3, 1, 0, 2>), grid, dim3(256), 0, s, a, ntiles);
+    else if (nt == 64) PP_LAUNCH(tg, (k_sep_u<64, 1, 3, 1, 0, 2>), grid, dim3(256), 0, s, a, ntiles);
+    else PP_LAUNCH(tg, (k_sep_u<32, 1, 3, 1, 0, 2>), grid, dim3(256), 0, s, a, ntiles);
+    return gx;
 #endif
 }
 

@@ -1872,6 +1872,8 @@ int train_buffers(pp_engine* e) {
             const size_t n = B * l.in_h * l.in_w * l.k * l.k * l.cout;
             A1(dalloc(e, &tb.Z, n));
             max_z = std::max(max_z, n);
+            tb.pw16_off = pw16_words;                       // the kernel as a GEMM operand [cin][k * k * cout], two float16 pieces
+            pw16_words += (long)2 * l.cin * l.k * l.k * l.cout;
         } else {
             continue;
         }
@@ -1887,12 +1889,13 @@ int train_buffers(pp_engine* e) {
         size_t need = 1;
         for (const LayerDesc& l : s.layers) {
             if (l.kind == LAYER_SEP) need = std::max(need, (B * l.out_h * l.out_w + 127) / 128 * 4 * 2 * (size_t)l.cout);
-            else if (l.kind == LAYER_DECONV) need = std::max(need, (B * l.in_h * l.in_w + 63) / 64 * 2 * (size_t)l.k * l.k * l.cout);
+            else if (l.kind == LAYER_DECONV) need = std::max(need, ((B * l.in_h * l.in_w + 63) / 64 + 8) * 2 * (size_t)l.k * l.k * l.cout);
         }
         A1(dalloc(e, &cx.stat_part, need));
         cx.stat_part_floats = (long)need;
     }
     A1(dalloc(e, &cx.pw16, (size_t)std::max<long>(pw16_words, 8)));
+    A1(dalloc(e, &cx.head_w16, (size_t)2 * s.CC * PP_HEAD_COLS));
     // split-K partial tiles + the regions of the step's deferred reductions (every weight gradient keeps its
     // partials until the end of the step): 64 MB at the reference's batch, 16 MB more per frame beyond 4
     // (round 4: capped -- the deferred regions are bounded by the SHAPES, not the batch: a weight-gradient product keeps at

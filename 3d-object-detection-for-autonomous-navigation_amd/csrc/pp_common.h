@@ -216,6 +216,18 @@ struct SepTrainArgs {
     const char* tag;             // profiler name of the launch ("k_sep_u_tr:<layer>")
 };
 int launch_sep_train(const SepTrainArgs& t, hipStream_t s);   // rows of `stat` written, 0: shape not supported
+// ... and of a plain product out[rows][N] = in[rows][K] . W (+ bias): the transposed convolutions' forward GEMMs, the heads
+struct RowsTrainArgs {
+    const float* in;             // [rows][K], rows contiguous (no header needed)
+    const unsigned short* wt16;  // W as two float16 pieces, [K / 16][2][N][16]
+    const float* bias;           // [N] or NULL
+    float* out;                  // [rows][ld_out]
+    float* stat;                 // statistics partials [rows written][2][N], or NULL
+    long long rows;
+    int K, N, ld_out;
+    const char* tag;
+};
+int launch_rows_train(const RowsTrainArgs& t, hipStream_t s);
 int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s,
                  int ablate = 0);  // returns 0 or PP_ERR_UNSUPPORTED
 

@@ -71,6 +71,7 @@ struct TrainCtx {
     // float16 pieces, [cin / 16][2][cout][16] per layer (k_tr_split_pw, once per step); NULL: not available.  The
     // maps those launches read (canvas, Z of in-block layers, A of block-final ones) carry a NaN header in front.
     unsigned short* pw16;
+    unsigned short* head_w16;   // the packed head matrix [CC][32] in the same form
     long stat_part_floats;
 };
 

@@ -767,6 +767,9 @@ static int wgrad_split(const TrainCtx& cx, int M, int N, int K) {
 // >= 256 until the launch has a workgroup or two per CU (the partial tiles are added at once: the next kernel reads C)
 static int dgrad_split(int M, int N, int K) {
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    // (round 4, measured and dropped: K slices for the long-K input gradients of the transposed convolutions whose 64 x 64
+    // tiles fill only half a resident round -- deconv3 at B=32: 640 workgroups x 64 chunks -- pair.deconv3 183.5 -> 173.9 us,
+    // and the 4.4 us + 20 MB of the extra reduction launch give it back: the step 3.569 -> 3.571 ms)
     if (tiles >= 256) return 1;
     return (int)std::max<long>(1, std::min<long>(512 / tiles, K / 256));
 }
@@ -1906,26 +1909,29 @@ __global__ __launch_bounds__(256) void k_tr_unpack_head_grads(const float* __res
     }
 }
 
-// This step's pointwise kernels as two float16 pieces each (hi = rne(w), mid = rne(w - hi)), in the operand layout
-// of the fused forward kernel (k_sep_u<..., TR = 1>): [cin / 16][piece][cout][16] per layer, from the Keras layout
-// [cin][cout] of the flat parameter buffer.  One launch for all separable layers.
-struct SplitPwJob { long src, dst; int cin, cout; long first; };     // src: floats into params; dst: 16-bit words; first: global pair index
-struct SplitPwTable { int n; long total; SplitPwJob job[32]; };
-__global__ __launch_bounds__(256) void k_tr_split_pw(const float* __restrict__ params, unsigned short* __restrict__ out, SplitPwTable t) {
+// This step's forward weights as two float16 pieces each (hi = rne(w), mid = rne(w - hi)), in the operand layout of the
+// fused forward kernels (k_sep_u<..., TR = 1 | 2>): [K / 16][piece][N][16] per product -- the pointwise kernels (Keras
+// [cin][cout]), the transposed convolutions' kernels as GEMM operands (Keras [k][k][cout][cin]: W(kk, n) = K[n][kk]) --
+// from the flat parameter buffer.  One launch for all of them; the packed head matrix follows in a launch of its own
+// (it is packed from the three head kernels just before).
+struct SplitPwJob { const float* src; long dst; int K, N; long sk, sn; long first; };   // W(k, n) = src[k * sk + n * sn]; dst: 16-bit words; first: global element index
+struct SplitPwTable { int n; long total; SplitPwJob job[40]; };
+__global__ __launch_bounds__(256) void k_tr_split_pw(unsigned short* __restrict__ out, SplitPwTable t) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;     // one weight per thread
     if (i >= t.total) return;
     int j = 0;
     while (j + 1 < t.n && i >= t.job[j + 1].first) ++j;
     const SplitPwJob q = t.job[j];
     const long e = i - q.first;
-    const int co = (int)(e % q.cout), ci = (int)(e / q.cout);                // consecutive threads: consecutive co (coalesced read)
-    const float w = params[q.src + e];
+    int k, n;                                                // consecutive threads walk the source's unit-stride axis
+    if (q.sn == 1) { n = (int)(e % q.N); k = (int)(e / q.N); } else { k = (int)(e % q.K); n = (int)(e / q.K); }
+    const float w = q.src[(long)k * q.sk + (long)n * q.sn];
     const _Float16 hf = (_Float16)w;
     const _Float16 mf = (_Float16)(w - (float)hf);
-    const int kc = ci >> 4, cc = ci & 15;
-    unsigned short* d = out + q.dst + (((long)kc * 2) * q.cout + co) * 16 + cc;
+    const int kc = k >> 4, cc = k & 15;
+    unsigned short* d = out + q.dst + (((long)kc * 2) * q.N + n) * 16 + cc;
     d[0] = __builtin_bit_cast(unsigned short, hf);
-    d[(long)q.cout * 16] = __builtin_bit_cast(unsigned short, mf);
+    d[(long)q.N * 16] = __builtin_bit_cast(unsigned short, mf);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2152,16 +2158,23 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
         int bi_ = 0, li_ = 0;
         for (size_t i = 0; i < s.layers.size() && fused; ++i) {
             const LayerDesc& l = s.layers[i];
+            if (l.kind != LAYER_SEP && l.kind != LAYER_DECONV) continue;
+            if (t.n >= 40) { fused = false; break; }
             if (l.kind == LAYER_SEP) {
-                if (t.n >= 32) { fused = false; break; }
                 const std::string pre = "rpn/block" + std::to_string(bi_ + 1) + "/" + std::to_string(li_);
-                t.job[t.n] = SplitPwJob{(long)(L.p(pre + "/pointwise_kernel") - params), cx.lbuf[i].pw16_off, l.cin, l.cout, t.total};
+                t.job[t.n] = SplitPwJob{L.p(pre + "/pointwise_kernel"), cx.lbuf[i].pw16_off, l.cin, l.cout, (long)l.cout, 1L, t.total};
                 t.total += (long)l.cin * l.cout;
-                ++t.n; ++li_;
-            } else if (l.kind == LAYER_DECONV) { ++bi_; li_ = 0; }
+                ++li_;
+            } else {
+                const int N = l.k * l.k * l.cout;
+                t.job[t.n] = SplitPwJob{L.p("rpn/deconv" + std::to_string(bi_ + 1) + "/kernel"), cx.lbuf[i].pw16_off, l.cin, N, 1L, (long)l.cin, t.total};
+                t.total += (long)l.cin * N;
+                ++bi_; li_ = 0;
+            }
+            ++t.n;
         }
         if (fused && t.n > 0)
-            PP_LAUNCH("k_tr_split_pw", k_tr_split_pw, dim3(blocks_for(t.total)), dim3(256), 0, cx.stream, params, cx.pw16, t);
+            PP_LAUNCH("k_tr_split_pw", k_tr_split_pw, dim3(blocks_for(t.total)), dim3(256), 0, cx.stream, cx.pw16, t);
     }
 
     // cur: what the next layer reads -- a tensor (cur_coef == NULL: the canvas, a block-final activation) or the
@@ -2223,8 +2236,26 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
             const int N = l.k * l.k * l.cout;
             if (cur_coef != nullptr) return PP_ERR_UNSUPPORTED;   // (a block always ends in a layer that keeps its activation)
             // Zs[m][tap * cout + co] = X[m][:] . K[tap][co][:]   (Keras Conv2DTranspose kernel [k, k, Cout, Cin])
+            int stat_rows = 0;
+            // (a product, not a map walk: what has to be large is the number of workgroup tiles -- deconv3 at B=32 is
+            // 10 240 rows x 2 048 columns = 1 280 tiles of 128 x 128)
+            const long wg_tiles = ((m + 127) / 128) * (long)(N / ((N % 128 == 0) ? 128 : ((N % 64 == 0) ? 64 : 32)));
+            if (fused && (m >= fused_min || (fused_min > 0 && wg_tiles >= 512)) &&
+                ((m + 127) / 128 + 8) * 2 * (long)N <= cx.stat_part_floats) {
+                static thread_local std::string tags[64];
+                std::string& tag = tags[i % 64];
+                tag = "k_sep_u_tr:deconv" + std::to_string(bi + 1);
+                RowsTrainArgs t;
+                t.in = cur; t.wt16 = cx.pw16 + tb.pw16_off; t.bias = nullptr; t.out = tb.Z; t.stat = cx.stat_part;
+                t.rows = m; t.K = l.cin; t.N = N; t.ld_out = N; t.tag = tag.c_str();
+                stat_rows = launch_rows_train(t, cx.stream);
+            }
+            if (stat_rows > 0) {
+                g_last_stat_tiles = stat_rows;
+            } else {
             gemm_tag("k_tr_gemm2:fwd.deconv" + std::to_string(bi + 1));
             tr_gemm(cx, cur, l.cin, 1, L.p(pre + "/kernel"), 1, l.cin, tb.Z, N, (int)m, N, l.cin, nullptr, 0, 1, cx.stat_part);
+            }
             const RowMap rm{l.k, l.in_h, l.in_w};
             bn_relu_forward(cx, tb.Z, m * l.k * l.k, l.cout, L.p(pre + "/bn/gamma"), L.p(pre + "/bn/beta"), tb.stats, tb.coef,
                             L.s(pre + "/bn/moving_mean"), L.s(pre + "/bn/moving_variance"), 0.99f, cx.cat, s.CC, co_off, rm,
@@ -2239,8 +2270,22 @@ int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainE
     PP_LAUNCH("k_tr_pack_heads", k_tr_pack_heads, dim3(blocks_for((long)s.CC * PP_HEAD_COLS)), dim3(256), 0, cx.stream,
               L.p("rpn/conv_box/kernel"), L.p("rpn/conv_cls/kernel"), kd, L.p("rpn/conv_box/bias"), L.p("rpn/conv_cls/bias"), bd,
               s.CC, nb, nc, nd, cx.head_w, cx.head_b);
+    int heads_done = 0;
+    if (fused && px >= fused_min && cx.head_w16 != nullptr) {
+        SplitPwTable t;
+        memset(&t, 0, sizeof(t));
+        t.n = 1; t.total = (long)s.CC * PP_HEAD_COLS;
+        t.job[0] = SplitPwJob{cx.head_w, 0L, s.CC, PP_HEAD_COLS, (long)PP_HEAD_COLS, 1L, 0L};
+        PP_LAUNCH("k_tr_split_pw", k_tr_split_pw, dim3(blocks_for(t.total)), dim3(256), 0, cx.stream, cx.head_w16, t);
+        RowsTrainArgs r;
+        r.in = cx.cat; r.wt16 = cx.head_w16; r.bias = cx.head_b; r.out = cx.head; r.stat = nullptr;
+        r.rows = px; r.K = s.CC; r.N = PP_HEAD_COLS; r.ld_out = PP_HEAD_COLS; r.tag = "k_sep_u_tr:heads";
+        heads_done = launch_rows_train(r, cx.stream);
+    }
+    if (!heads_done) {
     gemm_tag("k_tr_gemm2:fwd.heads");
     tr_gemm(cx, cx.cat, s.CC, 1, cx.head_w, PP_HEAD_COLS, 1, cx.head, PP_HEAD_COLS, (int)px, PP_HEAD_COLS, s.CC, cx.head_b, 0, 1);
+    }
     }   // forward
     if (!(phase & 2)) return PP_OK;
 

@@ -327,3 +327,19 @@ def test_voxelnet_training_call_surface(pp, hip_lib):
         eng.train_step_wait()
     assert eng.stream_ptr() != 0
     net.trainer.close()
+
+
+def test_fused_forward_kernels_on_small_grids(hip_lib):
+    """The fused training-forward launches (k_sep_u<..., TR = 1>: depthwise + product + statistics of a separable layer;
+    TR = 2: the transposed convolutions' and the heads' forward products) only run from 32 768 output rows on by default,
+    so the autograd tests above (640-row maps) time the separate kernels.  One child process with PP_TRAIN_FUSED_MIN=0 --
+    the switch is read once per process -- runs the same six autograd comparisons through the fused launches: ragged
+    tiles (640 / 160 / 40 rows), every tile width (32 / 64 / 128 output channels), stride 1 and 2, the NaN padding header
+    on 20 x 16 maps, head bias."""
+    env = dict(os.environ)
+    env["PP_TRAIN_FUSED_MIN"] = "0"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_train.py"), "-k", "small_grids and not fused_forward"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "6 passed" in r.stdout, r.stdout[-1000:]
