@@ -98,6 +98,18 @@ def test_kitti_shaped_batch32_two_classes(pp, hip_lib):
         assert len(np.unique(flat)) == P and (im["coors"][b, :P, 0] == 0).all()
         assert im["num_points"][b, :P].min() >= 1 and im["num_points"][b, :P].max() <= d.max_points
     assert labels_seen == {0, 1}, labels_seen
+    # the feed the bench uses: page-locked staging, voxelised at upload time on the copy stream into the handle's OTHER set
+    # of voxeliser products (cell map, CSR, occupancy bitmap), three uploads so that both sets are used -- same bits
+    st = eng.staging(frames)
+    for _ in range(3):
+        eng.upload_async(st)
+        eng.detect_async()
+        dets3, n3 = eng.detections()
+        assert np.array_equal(n, n3) and dets.tobytes() == dets3.tobytes(), "upload-time voxeliser path"
+    im3 = eng.intermediates()
+    assert np.array_equal(im3["n_pillars"], im["n_pillars"]) and np.array_equal(im3["coors"], im["coors"])
+    assert np.array_equal(im3["anchors_mask"], im["anchors_mask"])
+    st.close()
     # eight frames against the oracle (pillar indices bit-exact, head maps and detections within 1e-4)
     for b in (0, 3, 7, 12, 17, 22, 30, 31):
         ref = util_ref.oracle_detect(d, w, [frames[b]], rect, trv, p2)
