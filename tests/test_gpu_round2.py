@@ -750,3 +750,36 @@ def test_predict_more_candidates_than_the_lds_buffer(pp, hip_lib, order):
     np.testing.assert_allclose(dets[0]["box3d_lidar"][:n[0]], ref["box3d_lidar"], rtol=1e-5, atol=1e-5)
     assert np.array_equal(dets[0]["label"][:n[0]], ref["label_preds"])
     eng.close()
+
+
+def test_float32_fallback_on_the_sparse_canvas_configuration(pp, hip_lib):
+    """pp_set_gemm_precision(PP_PREC_F32) on the KITTI-shaped configuration: the sparse canvas (whose first layer only the
+    split-precision kernels understand) is switched off with the float16 pieces, the dense PFN + float32 kernels run the
+    same resident frames, and the results match the split-precision pass within the 1e-4 bar and the oracle."""
+    B, N = 2, 20000
+    cfg = pp.config.kitti_shaped_config(B, num_class=2)
+    eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=N)
+    d = eng.d
+    w = pp.weights.init_weights(d, seed=5)
+    eng.load_weights(w)
+    frames = [pp.synth.kitti_cloud(700 + i, N) for i in range(B)]
+    rect, trv, p2 = pp.synth.default_calib()
+    R, T = np.stack([rect] * B), np.stack([trv] * B)
+    dets, n = eng.detect(frames, R, T)
+    im = eng.intermediates()
+    eng.set_gemm_precision("f32")
+    assert eng.gemm_precision() == "f32"
+    eng.detect_async()                       # the frames are still resident
+    dets32, n32 = eng.detections()
+    im32 = eng.intermediates()
+    assert np.array_equal(im32["coors"], im["coors"]) and np.array_equal(im32["anchors_mask"], im["anchors_mask"])
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        np.testing.assert_allclose(im32[k], im[k], rtol=0, atol=TOL)
+    ref = util_ref.oracle_detect(d, w, [frames[1]], rect, trv, p2)
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        np.testing.assert_allclose(im32[k][1], ref["preds"][k][0], rtol=0, atol=TOL)
+    _assert_dets([pp.VoxelNet._to_dict(dets32[1], int(n32[1]), 0)], ref["dets"])
+    eng.set_gemm_precision("split_f16")
+    dets2, n2 = eng.detect(frames, R, T)
+    assert np.array_equal(n2, n) and dets2.tobytes() == dets.tobytes(), "back on the split path: the same bits as before"
+    eng.close()
