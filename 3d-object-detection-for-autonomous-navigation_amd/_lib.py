@@ -29,7 +29,7 @@ EXPORTS = [
     "pp_set_anchors", "pp_points_to_voxel", "pp_anchor_mask", "pp_forward_voxels", "pp_predict",
     "pp_upload_points", "pp_upload_points_async", "pp_host_alloc", "pp_host_free", "pp_upload_points_device",
     "pp_current_batch", "pp_set_calib", "pp_detect_async", "pp_sync",
-    "pp_get_detections", "pp_set_gemm_precision", "pp_get_gemm_precision", "pp_detect", "pp_fetch_intermediates", "pp_set_profiling", "pp_get_kernel_times",
+    "pp_get_detections", "pp_set_gemm_precision", "pp_get_gemm_precision", "pp_set_cache_budget", "pp_detect", "pp_fetch_intermediates", "pp_set_profiling", "pp_get_kernel_times",
     "pp_timer_start", "pp_timer_stop", "pp_device_info", "pp_device_copy_bench", "pp_device_mem_free", "pp_bench_layer", "pp_layer_count", "pp_layer_tag",
     "pp_rotate_iou_eval", "pp_d3_box_overlap", "pp_head_loss", "pp_adamw_step_device",
     "pp_train_layout", "pp_train_layout_entry", "pp_train_step", "pp_train_step_async", "pp_train_step_wait",
@@ -219,6 +219,7 @@ def lib():
     L.pp_get_detections.argtypes = [vp, vp, vp]
     L.pp_set_gemm_precision.argtypes = [vp, i32]
     L.pp_get_gemm_precision.argtypes = [vp, ctypes.POINTER(i32)]
+    L.pp_set_cache_budget.argtypes = [vp, i32]
     L.pp_detect.argtypes = [vp, f32p, vp, i32, f32p, f32p, vp, vp]
     L.pp_fetch_intermediates.argtypes = [vp, vp, vp, vp, vp, f32p, f32p, f32p, f32p]
     L.pp_set_profiling.argtypes = [vp, i32]

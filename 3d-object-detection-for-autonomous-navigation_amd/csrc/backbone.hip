@@ -111,6 +111,8 @@ struct GemmArgs {
     const float* head_bias;   // [PP_HEAD_COLS]
     int head_mode;            // 0: none, 1: head = partial + bias, 2: head += partial
     int M;                // GEMM rows (pixels) < 2^31 (checked by the launcher)
+    int tile_lo;          // k_sep_u: first 128-pixel tile of this launch (a launch over the frames [f0, f1) of a batch walks
+                          // the tiles [f0 * hw / 128, ceil(f1 * hw / 128)) of the whole batch's pixel space, M = f1 * hw)
     int dbg;              // tuning aid: ablation bits (pp_bench_layer), 0 in production
     long long* stamps;    // tuning aid (dbg & 64): [block<64][role 2][iter 40][4] shader-clock stamps
     int in_h, in_w, cin;
@@ -833,7 +835,8 @@ __global__ __launch_bounds__(256, WPS) void k_sep_u(GemmArgs a, int ntiles) {
     // range [x * ntiles / 8, (x + 1) * ntiles / 8); its workgroups walk that range together, so the halo
     // rows two neighbouring tiles share are served by one L2 ----
     const int xcd = blockIdx.x & 7, gl = blockIdx.x >> 3, GL = gridDim.x >> 3;
-    const int tbase = (int)(((long long)xcd * ntiles) >> 3), tend = (int)(((long long)(xcd + 1) * ntiles) >> 3);
+    const int nt_ = ntiles - a.tile_lo;                // tiles of this launch: [tile_lo, ntiles)
+    const int tbase = a.tile_lo + (int)(((long long)xcd * nt_) >> 3), tend = a.tile_lo + (int)(((long long)(xcd + 1) * nt_) >> 3);
     const int first = tbase + gl;
     const int n0 = blockIdx.y * NT;
     if (first >= tend) {                               // uniform for the workgroup
@@ -1226,7 +1229,8 @@ static void launch_u(const GemmArgs& a, int n_total, hipStream_t s) {
     const int ny = n_total / NT;
     const bool bf = a.wt16 != nullptr && split_precision(a.dbg);
     int slots = (g_num_cus * (bf ? WPB : WPS)) / ny;
-    int gx = ntiles < slots ? ntiles : slots;
+    const int mine = ntiles - a.tile_lo;               // (a.tile_lo > 0: a launch over a sub-range of the batch's frames)
+    int gx = mine < slots ? mine : slots;
     gx = (gx + 7) & ~7;
     dim3 grid((unsigned)gx, ny);
     if (bf && a.occ != nullptr)
@@ -2692,7 +2696,16 @@ bool layer_writes_cls_plane(const LayerDesc& L) {
     return L.kind == LAYER_DECONV && L.head_mode == 2 && L.d_cls_plane != nullptr && deconv_uniform(L, 0);
 }
 
-int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, int ablate) {
+// frame0 > 0 (separable layers on k_sep_u only, launch_layer_subrange_ok): the launch covers the frames [frame0, frame0 +
+// batch) of a larger batch -- same buffers, same pixel numbering, a sub-range of the tiles
+bool launch_layer_subrange_ok(const LayerDesc& L, int frame0, int batch, int total_batch) {
+    if (L.kind != LAYER_SEP) return false;
+    const long long hw = (long long)L.out_h * L.out_w;
+    if ((frame0 * hw) % PX_TILE != 0) return false;
+    return layer_kernel_name(L, batch).compare(0, 8, "k_sep_u<") == 0 && layer_kernel_name(L, total_batch).compare(0, 8, "k_sep_u<") == 0;
+}
+
+int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, int ablate, int frame0) {
     if (batch <= 0) return 0;
     if (L.cin % KC != 0) return PP_ERR_UNSUPPORTED;
     {
@@ -2703,6 +2716,7 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
     GemmArgs a;
     a.dbg = ablate;
     a.stamps = g_stamps;
+    a.tile_lo = 0;
     a.in = L.in; a.dw = L.d_dw; a.wt = L.d_wt; a.bias = L.d_bias; a.out = L.out;
     a.wt16 = reinterpret_cast<const unsigned short*>(L.d_wt16); a.n_total = L.n_total;
     a.head = d_head; a.head_wt = L.d_head_wt; a.head_bias = L.d_head_bias; a.head_mode = L.head_mode;
@@ -2717,20 +2731,25 @@ int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s, in
     a.cls_col0 = L.cls_col0; a.cls_ncol = L.cls_ncol;
     if (L.kind == LAYER_SEP) {
         a.px_h = L.out_h; a.px_w = L.out_w; a.epi = 0;
-        a.M = batch * L.out_h * L.out_w;
+        a.M = (frame0 + batch) * L.out_h * L.out_w;
+        if (frame0 > 0) {
+            if (!launch_layer_subrange_ok(L, frame0, batch, frame0 + batch)) return PP_ERR_UNSUPPORTED;
+            a.tile_lo = (int)(((long long)frame0 * L.out_h * L.out_w) / PX_TILE);
+        }
         if (L.cout % 32 != 0) return PP_ERR_UNSUPPORTED;
         // a sparse input is only understood by the split-precision uniform-wave / split-K kernels
         if (a.occ != nullptr && !(sparse_input_supported(L, batch) && split_precision(ablate) && sep_uniform(ablate)))
             return PP_ERR_UNSUPPORTED;
         if (use_ws(L) && sep_uniform(ablate) && a.M < (1 << 24)) {   // k_sep_u's float-reciprocal index math
             const int nt = sep_u_nt(L, batch);
+            const long long msel = (long long)batch * L.out_h * L.out_w;    // rows of THIS launch (a.M is the end of its pixel range)
 #if PP_SPLIT_MODE != 0
-            if (!sep_k4_runs(a.wt16, a.cin, L.n_total, a.M, ablate) &&
-                sep_p_runs(a.wt16, L.stride, a.cin, L.cout, L.n_total, a.M, a.occ, ablate)) {   // depthwise once for 256 channels
+            if (!sep_k4_runs(a.wt16, a.cin, L.n_total, msel, ablate) &&
+                sep_p_runs(a.wt16, L.stride, a.cin, L.cout, L.n_total, msel, a.occ, ablate)) {   // depthwise once for 256 channels
                 launch_p(a, s);
             } else
 #endif
-            if (!(ablate & 16) && sep_k4_runs(a.wt16, a.cin, L.n_total, a.M, ablate)) {   // small map
+            if (!(ablate & 16) && sep_k4_runs(a.wt16, a.cin, L.n_total, msel, ablate)) {   // small map
                 if (L.stride == 1) launch_k4<1>(a, L.n_total, s);
                 else launch_k4<2>(a, L.n_total, s);
             } else if (L.stride == 1) {

@@ -61,6 +61,7 @@ struct pp_engine {
         unsigned long long* occbits = nullptr;
         bool occ_cleared = false;         // its k_cell_first cleared the occupancy bitmap (consumed by run_pfn)
     } vox[2];
+    int cache_budget_mb = 256;            // run_backbone's frame sub-ranges (pp_set_cache_budget; 0 = off)
     bool vox_ahead = false;               // the resident batch was voxelised at upload time (pp_detect_async skips it)
     bool prevox_issued = false;           // a voxeliser launch is (or was) queued on the copy stream: a main-stream one waits for ev_up
     int results_buf = 0;                  // set the last pp_detect_async read (pp_fetch_intermediates)
@@ -543,13 +544,57 @@ int run_backbone(pp_engine* e, int batch) {
     refresh_tags(e, batch);
     e->cls_plane_live = false;
     for (const LayerDesc& L : e->layers) if (layer_writes_cls_plane(L)) e->cls_plane_live = true;
-    for (size_t i = 0; i < e->layers.size(); ++i) {
-        LayerDesc L = e->layers[i];
-        // sparse first layer: the occupancy bitmap when this pass's PFN launch left one, else the cell map
-        if (i == 0 && L.d_occ != nullptr) { L.d_occ = e->d_cellmap; L.d_occbits = e->occbits_live ? e->d_occbits : nullptr; }
-        ProfScope ps(e, e->layer_tags[i].c_str());
-        int st = launch_layer(L, batch, e->d_head, e->stream);
-        if (st) return fail(e, st, "layer %s: unsupported shape (cin=%d cout=%d)", L.name, L.cin, L.cout);
+    // Frame sub-ranges for the layers whose maps do not fit the last-level cache (round 4).  A run of consecutive
+    // separable layers of a block is walked sub-batch by sub-batch -- L1(s0) L2(s0) L3(s0), L1(s1) ... -- so that what a
+    // layer reads is what the layer before has just written for the same frames and still sits in the 256 MB cache:
+    // on the KITTI-shaped B = 32 maps (439 MB in block1, 219 MB in block2) a layer's loads are a third of its time, on
+    // cfg-A's 84-168 MB maps they are free already.  Same kernels, same buffers, same pixel
+    // numbering: a launch walks a sub-range of the batch's tiles (launch_layer's frame0).  The budget (input + output map
+    // of a launch) is the handle's cache_budget_mb: pp_set_cache_budget, default 256 = the whole cache for ONE handle in
+    // flight; callers that keep several handles in flight set 0 -- their working sets evict each other and the extra
+    // launches only cost (measured: DESIGN section 4.6).
+    const int sub_on = e->cache_budget_mb > 0 ? 1 : 0;
+    const long sub_mb = e->cache_budget_mb;
+    size_t i = 0;
+    while (i < e->layers.size()) {
+        // the run [i, j) of separable layers, and the sub-batch it is walked in (1 = the whole batch)
+        size_t j = i;
+        int sub = batch;
+        if (sub_on && e->layers[i].kind == LAYER_SEP) {
+            double per_frame = 0.0;          // bytes of the largest (input + output) map pair of the run, per frame
+            while (j < e->layers.size() && e->layers[j].kind == LAYER_SEP) {
+                const LayerDesc& l = e->layers[j];
+                const double in_b = (j == 0 && l.d_occ != nullptr) ? 0.0 : 4.0 * l.in_h * l.in_w * l.cin;   // (the sparse canvas is not read as a map)
+                per_frame = std::max(per_frame, in_b + 4.0 * l.out_h * l.out_w * l.cout);
+                ++j;
+            }
+            const double budget = (double)sub_mb * 1048576.0;
+            while (sub > 1 && per_frame * sub > budget && sub % 2 == 0) sub /= 2;
+            // every launch must stay a full-chip k_sep_u launch whose sub-range starts on a tile boundary
+            for (bool ok = false; sub < batch && !ok; ) {
+                ok = true;
+                for (size_t k = i; k < j && ok; ++k)
+                    for (int f0 = 0; f0 < batch && ok; f0 += sub)
+                        ok = launch_layer_subrange_ok(e->layers[k], f0, std::min(sub, batch - f0), batch) &&
+                             (long long)sub * e->layers[k].out_h * e->layers[k].out_w >= 1024ll * 128;
+                if (!ok) sub *= 2;
+            }
+            if (sub >= batch) sub = batch;
+        } else {
+            j = i + 1;
+        }
+        for (int f0 = 0; f0 < batch; f0 += sub) {
+            const int nb = std::min(sub, batch - f0);
+            for (size_t k = i; k < j; ++k) {
+                LayerDesc L = e->layers[k];
+                // sparse first layer: the occupancy bitmap when this pass's PFN launch left one, else the cell map
+                if (k == 0 && L.d_occ != nullptr) { L.d_occ = e->d_cellmap; L.d_occbits = e->occbits_live ? e->d_occbits : nullptr; }
+                ProfScope ps(e, e->layer_tags[k].c_str());
+                int st = launch_layer(L, nb, e->d_head, e->stream, 0, f0);
+                if (st) return fail(e, st, "layer %s: unsupported shape (cin=%d cout=%d)", L.name, L.cin, L.cout);
+            }
+        }
+        i = j;
     }
     HIPCHK(e, hipGetLastError());
     return PP_OK;
@@ -687,6 +732,12 @@ int pp_create(const pp_config* cfg, int device, pp_handle* out) {
     pp_engine* e = new pp_engine();
     e->cfg = *cfg;
     e->device = device;
+    {   // PP_SUBBATCH=0 / PP_SUBBATCH_MB=n: the default of pp_set_cache_budget for handles of this process
+        const char* s0 = getenv("PP_SUBBATCH");
+        const char* s1 = getenv("PP_SUBBATCH_MB");
+        if (s1) e->cache_budget_mb = std::max(0, atoi(s1));
+        if (s0 && s0[0] == '0') e->cache_budget_mb = 0;
+    }
     hipError_t st = hipSetDevice(device);
     if (st == hipSuccess) {
         const int part = cu_partition();
@@ -1414,6 +1465,16 @@ int pp_set_gemm_precision(pp_handle e, int32_t precision) {
     e->force_f32 = f32;
     if (!e->weights_ready) return PP_OK;
     return pp_finalize_weights(e);       // waits for the stream, drops the graphs, rebuilds the device weights
+}
+
+int pp_set_cache_budget(pp_handle e, int32_t megabytes) {
+    if (!e) return PP_ERR_ARG;
+    if (megabytes < 0) return fail(e, PP_ERR_ARG, "pp_set_cache_budget: negative budget");
+    if (megabytes == e->cache_budget_mb) return PP_OK;
+    (void)hipSetDevice(e->device);
+    graph_invalidate(e);          // the captured passes hold the old launch plan
+    e->cache_budget_mb = megabytes;
+    return PP_OK;
 }
 
 int pp_get_gemm_precision(pp_handle e, int32_t* precision) {

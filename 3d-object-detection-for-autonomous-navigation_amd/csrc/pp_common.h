@@ -229,7 +229,9 @@ struct RowsTrainArgs {
 };
 int launch_rows_train(const RowsTrainArgs& t, hipStream_t s);
 int launch_layer(const LayerDesc& L, int batch, float* d_head, hipStream_t s,
-                 int ablate = 0);  // returns 0 or PP_ERR_UNSUPPORTED
+                 int ablate = 0, int frame0 = 0);
+// may L be launched over the frames [frame0, frame0 + batch) of a total_batch-frame batch (k_sep_u's tile sub-ranges)?
+bool launch_layer_subrange_ok(const LayerDesc& L, int frame0, int batch, int total_batch);  // returns 0 or PP_ERR_UNSUPPORTED
 
 struct PostParams {
     int batch;

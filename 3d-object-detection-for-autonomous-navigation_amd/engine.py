@@ -171,6 +171,12 @@ class Engine:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self._check(self._lib.pp_set_gemm_precision(self._h, _PRECISIONS[precision]), "pp_set_gemm_precision")
 
+    def set_cache_budget(self, megabytes):
+        """Last-level-cache budget of a pass in MiB (pp_set_cache_budget; default 256, 0 = off): layers whose maps exceed
+        it run over sub-ranges of the batch's frames.  Right for one engine in flight per GPU; set 0 when several
+        engines share the GPU (their working sets evict each other)."""
+        self._check(self._lib.pp_set_cache_budget(self._h, int(megabytes)), "pp_set_cache_budget")
+
     def gemm_precision(self):
         v = ctypes.c_int32(0)
         self._check(self._lib.pp_get_gemm_precision(self._h, ctypes.byref(v)), "pp_get_gemm_precision")

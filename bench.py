@@ -205,6 +205,10 @@ class Feeder:
 
     def __init__(self, engines, stagings, upload=True):
         self.engines, self.stagings, self.upload = engines, stagings, upload
+        # one engine in flight: its passes get the whole last-level cache (frame sub-ranges for maps that do not fit,
+        # pp_set_cache_budget); several: off -- their working sets evict each other and the extra launches only cost
+        for e in engines:
+            e.set_cache_budget(256 if len(engines) == 1 else 0)
         self.busy = [False] * len(engines)
         self.i = 0
         self.n_det = 0          # detections the host has read (checksum of the consumed results)
@@ -291,7 +295,9 @@ def summarise(samples, steps):
         a[0] += mean * len(ms_list)
         a[1] += len(ms_list)
         if layer:
-            per_layer[layer] = (mean, sym)
+            # (mean launch ms, symbol, launches of this layer per step: > 1 when the engine walks a layer over
+            # sub-ranges of the batch's frames, pp_set_cache_budget)
+            per_layer[layer] = (mean, sym, len(ms_list) / steps)
     kernel_ms = {k: v[0] / steps for k, v in agg.items()}
     launches = {k: v[1] / steps for k, v in agg.items()}
     return kernel_ms, launches, per_layer, dropped
@@ -304,11 +310,13 @@ def kernel_roofs(d, B, n_points, n_pillars, kernel_ms, launches, per_layer, head
     out = {}
     for sym, ms in kernel_ms.items():
         t = ms / launches[sym] * 1e-3
-        mine = [layer for layer, (_, s) in per_layer.items() if s == sym and layer in lf]
+        mine = [layer for layer, v in per_layer.items() if v[1] == sym and layer in lf]
         r = {"avg_launch_ms": ms / launches[sym], "launches_per_step": launches[sym]}
         if mine:
-            fl = sum(lf[n] for n in mine) / len(mine)
-            by = sum(lb[n] for n in mine) / len(mine)
+            # per launch: the layers' work over the launches they took (a layer walked in four sub-ranges is four launches)
+            nl = sum(per_layer[n][2] for n in mine)
+            fl = sum(lf[n] for n in mine) / nl
+            by = sum(lb[n] for n in mine) / nl
             split = is_split_kernel(sym)
             peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_TERMS if split else F32_MFMA_PEAK_TFLOPS
             r.update({"algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
@@ -392,7 +400,7 @@ def cfgk_leg(pp, local_rank, steps=12, only_inflight=None):
             out["roofline"]["traffic_source"] = src
     except Exception as ex:
         out["roofline"]["traffic_source"] = {"error": repr(ex)}
-    out["layer_ms"] = {k: round(v[0], 4) for k, v in per_layer.items()}
+    out["layer_ms"] = {k: round(v[0] * v[2], 4) for k, v in per_layer.items()}     # per step (all sub-range launches of the layer)
     for s in stagings:
         s.close()
     for e in engines:
@@ -707,14 +715,14 @@ def main():
     # kernel's `frac` alone flatters the step: the other GEMM layers sit lower)
     lb_all = layer_bytes(d, B, heads_fused, npil)
     bb_bytes = sum(lb_all[layer] for layer in layer_iso if layer in lb_all)
-    bb_ms = sum(layer_iso[layer][0] for layer in layer_iso if layer in lb_all)
+    bb_ms = sum(layer_iso[layer][0] * layer_iso[layer][2] for layer in layer_iso if layer in lb_all)
     lf_all = layer_flops(d, B, heads_fused)
     bb_flops = sum(lf_all[layer] for layer in layer_iso if layer in lf_all)
     lf = layer_flops(d, B, heads_fused)
     extras.update({
         "kernel_ms_per_step_overlapped": {k: round(v, 4) for k, v in sorted(k_ovl.items(), key=lambda kv: -kv[1])},
         "kernel_ms_per_step_inflight1": {k: round(v, 4) for k, v in sorted(k_iso.items(), key=lambda kv: -kv[1])},
-        "layer_ms_inflight1": {k: round(v[0], 4) for k, v in layer_iso.items()},
+        "layer_ms_inflight1": {k: round(v[0] * v[2], 4) for k, v in layer_iso.items()},
         "sum_kernel_ms_per_step_inflight1": sum(k_iso.values()),
         "sum_kernel_ms_per_step_overlapped": sum(k_ovl.values()),
         "kernel_time_over_wall": sum(k_ovl.values()) / ms_per_step,   # > 1: kernels of the in-flight batches overlap

@@ -214,6 +214,13 @@ int pp_get_detections(pp_handle h, pp_detection* dets, int32_t* n_dets);
  * environment (PP_GEMM_PREC=f32) or is PP_PREC_SPLIT_F16. */
 int pp_set_gemm_precision(pp_handle h, int32_t precision);
 int pp_get_gemm_precision(pp_handle h, int32_t* precision);
+/* Last-level-cache budget of a pass, in MiB (default 256, 0 = off).  Layers whose input + output maps exceed it are run
+ * over sub-ranges of the batch's frames, a block's consecutive separable layers sub-range by sub-range, so that a layer
+ * reads what the layer before has just written while it still sits in the 256 MB cache (KITTI-shaped B = 32: -5 % per
+ * pass; the shipped 80 x 64 grid fits as it is).  Results do not change.  Right for ONE handle in flight per GPU; a
+ * caller that keeps several handles in flight (bench.py's feeder) sets 0: their working sets evict each other.
+ * No reference counterpart (TensorFlow's executor owns that schedule).  Waits for the handle's stream. */
+int pp_set_cache_budget(pp_handle h, int32_t megabytes);
 /* Convenience: upload + calib + detect + sync + get (the evaluate loop body,
  * train.py:689-786 minus annotation formatting). */
 int pp_detect(pp_handle h, const float* points, const int32_t* frame_offsets, int32_t batch,

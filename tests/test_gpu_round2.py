@@ -98,6 +98,22 @@ def test_kitti_shaped_batch32_two_classes(pp, hip_lib):
         assert len(np.unique(flat)) == P and (im["coors"][b, :P, 0] == 0).all()
         assert im["num_points"][b, :P].min() >= 1 and im["num_points"][b, :P].max() <= d.max_points
     assert labels_seen == {0, 1}, labels_seen
+    # frame sub-ranges (pp_set_cache_budget): with the default budget block1's layers run as four launches of 8 frames and
+    # block2's as two of 16, walked sub-range by sub-range; without it one launch per layer -- and the same bits
+    def launches_of(layer):
+        eng.set_profiling(True)
+        d_, n_ = eng.detect(frames, np.stack([rect] * B), np.stack([trv] * B))
+        k = sum(1 for name, _ in eng.kernel_times() if name.endswith(":" + layer))
+        eng.set_profiling(False)
+        return k, d_, n_
+    k1, d1, n1 = launches_of("block1.2")
+    k2, _, _ = launches_of("block2.3")
+    assert (k1, k2) == (4, 2), (k1, k2)
+    assert np.array_equal(n1, n) and d1.tobytes() == dets.tobytes()
+    eng.set_cache_budget(0)
+    k0, d0, n0 = launches_of("block1.2")
+    assert k0 == 1 and np.array_equal(n0, n) and d0.tobytes() == dets.tobytes(), "sub-ranges do not change a bit"
+    eng.set_cache_budget(256)
     # the feed the bench uses: page-locked staging, voxelised at upload time on the copy stream into the handle's OTHER set
     # of voxeliser products (cell map, CSR, occupancy bitmap), three uploads so that both sets are used -- same bits
     st = eng.staging(frames)
