@@ -798,6 +798,7 @@ def main():
             # ... and at 64 frames per GPU: the small-map layers and the PFN are latency-bound at 32 (one round of
             # workgroups, chip half empty), so samples/s still rises with the batch
             extras["train_b64"] = train_leg(pp, local_rank, rank, n_gpus, dist, comm_dev, barrier, steps=8, batch=64)
+            extras["train_b128"] = train_leg(pp, local_rank, rank, n_gpus, dist, comm_dev, barrier, steps=6, batch=128)
         except Exception as ex:
             if dist is not None:
                 raise
