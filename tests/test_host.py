@@ -224,3 +224,26 @@ def test_one_hip_runtime_per_process(order):
     assert r.returncode == 0, r.stderr[-800:]
     line = [l for l in r.stdout.splitlines() if l.startswith("N ")][0]
     assert line.split()[1] == "1", line
+
+
+def test_bench_accounts_per_launch_when_a_layer_is_walked_in_sub_ranges(pp):
+    """bench.py's roofline arithmetic: a layer the engine walks in four frame sub-ranges (pp_set_cache_budget) is four
+    launches per step -- algorithmic bytes / flops per LAUNCH are the layer's divided by four, the layer's time per step
+    is the sum of its launches, and a whole-batch layer of the same symbol still counts as one."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    d = pp.config.Derived(pp.config.kitti_shaped_config(32, num_class=2))
+    steps = 3
+    samples = {"k_sep_u<64,1,3,1,0>:block1.1": [0.055] * (4 * steps),      # four sub-range launches per step
+               "k_sep_u<64,1,3,1,0>:block1.2": [0.220] * steps,            # one whole-batch launch per step
+               "k_postprocess": [0.06] * steps}
+    kernel_ms, launches, per_layer, dropped = bench.summarise(samples, steps)
+    assert dropped == 0 and launches["k_sep_u<64,1,3,1,0>"] == 5
+    assert per_layer["block1.1"][2] == 4 and per_layer["block1.2"][2] == 1
+    assert abs(kernel_ms["k_sep_u<64,1,3,1,0>"] - 0.44) < 1e-9
+    roofs = bench.kernel_roofs(d, 32, 20000, 5800.0, kernel_ms, launches, per_layer, True)
+    lb = bench.layer_bytes(d, 32, True, 5800.0)
+    r = roofs["k_sep_u<64,1,3,1,0>"]
+    assert abs(r["algorithmic_bytes_per_launch"] - (lb["block1.1"] + lb["block1.2"]) / 5) < 1.0
+    assert abs(r["avg_launch_ms"] - 0.44 / 5) < 1e-9
