@@ -5,7 +5,7 @@ The directory name is not a Python identifier; import it with
 `importlib.import_module("3d-object-detection-for-autonomous-navigation_amd")`
 or through the root-level alias module `pp_amd`.
 """
-from . import config, anchors, weights, synth, frame_shard, anno, kitti_eval, ingest, target_assigner, optim  # noqa: F401  (host-side modules)
+from . import config, anchors, weights, synth, frame_shard, anno, kitti_eval, ingest, target_assigner, optim, h5lite  # noqa: F401  (host-side modules)
 from . import _lib  # noqa: F401  (ctypes binding of the C-ABI; loads lazily)
 from .voxel_generator import points_to_voxel  # noqa: F401
 from .engine import Engine, NumericError  # noqa: F401

@@ -17,6 +17,8 @@ or, from raw clouds, `net.train_step(frames, labels, reg_targets, dist)`.  The f
 gradients of a call come from one `pp_train_step` (csrc/train.hip); the padded voxel tensor is unpadded on the
 host into the pillar-ordered point list it was built from (the voxeliser then reproduces the same pillars).
 """
+import os
+
 import numpy as np
 
 from . import weights as _weights
@@ -43,10 +45,11 @@ class VoxelNet:
         else:
             self.engine = Engine(self.d, **self._ctor)
 
-    # net.load_weights (train.py:731-734).  Accepts a dict name -> array (Keras
-    # layouts, weights.py) or an .npz written by weights.save_npz.
+    # net.load_weights (train.py:731-734).  Accepts a dict name -> array (Keras layouts, weights.py), an .npz written by
+    # weights.save_npz, or the reference's own checkpoint file (`model_weights_<epoch>.h5`, Keras save_weights,
+    # train.py:407,436: weights.load_keras_h5, with h5py when it is installed and the built-in reader otherwise).
     def load_weights(self, src):
-        w = _weights.load_npz(src) if isinstance(src, str) else src
+        w = _weights.load_any(src, self.d) if isinstance(src, (str, os.PathLike)) else src
         if self.training:
             if self.trainer is None:
                 self.trainer = Trainer(self.config, w, **self._ctor)

@@ -172,19 +172,53 @@ def map_keras_weight_names(keras_names, d):
     return out
 
 
-def from_keras_h5(group, d):
-    """`group`: an open h5py.File of a Keras `save_weights` checkpoint (root attribute `layer_names`, one group per
-    top-level layer with the attribute `weight_names` and one dataset per variable) -- or any object with the same
-    mapping interface (the unit test uses plain dicts).  Returns this package's weight dict, shapes verified."""
+def _h5_names(attrs, name):
+    """A name list attribute the way Keras reads it back (`load_attributes_from_hdf5_group`): `name`, or -- when the list
+    was too large for one object-header attribute -- its pieces `name0`, `name1`, ..."""
     def _s(x):
         return x.decode() if isinstance(x, bytes) else str(x)
+    if name in attrs:
+        return [_s(x) for x in np.asarray(attrs[name]).ravel().tolist()] if np.asarray(attrs[name]).size else []
+    out, i = [], 0
+    while f"{name}{i}" in attrs:
+        out += [_s(x) for x in np.asarray(attrs[f"{name}{i}"]).ravel().tolist()]
+        i += 1
+    return out
+
+
+def from_keras_h5(group, d):
+    """`group`: an open HDF5 file of a Keras `save_weights` checkpoint (root attribute `layer_names`, one group per
+    top-level layer with the attribute `weight_names` and one dataset per variable) through h5py.File or this package's
+    h5lite.File -- or any object with the same mapping interface (a unit test uses plain dicts).  Returns this
+    package's weight dict, shapes verified."""
     names, data = [], {}
-    for ln in group.attrs["layer_names"]:
-        g = group[_s(ln)]
-        for wn in g.attrs.get("weight_names", []):
-            names.append(_s(wn))
-            data[_s(wn)] = np.asarray(g[_s(wn)], dtype=np.float32)
+    for ln in _h5_names(group.attrs, "layer_names"):
+        g = group[ln]
+        for wn in _h5_names(g.attrs, "weight_names"):
+            names.append(wn)
+            data[wn] = np.asarray(g[wn], dtype=np.float32)
     mapping = map_keras_weight_names(names, d)
     w = {name: np.ascontiguousarray(data[kn]) for name, kn in mapping.items() if name in expected_shapes(d)}
     check_weights(d, w)
     return w
+
+
+def load_keras_h5(path, d):
+    """Reads the reference's checkpoint file `model_weights_<epoch>.h5` (net.save_weights, train.py:407,436; read back
+    by net.load_weights, train.py:731-734) into this package's weight dict.  h5py is used when the interpreter has it;
+    otherwise the built-in reader (h5lite.py: the part of the HDF5 format such files use, checked against files written
+    by the real library) -- the importer does not depend on a package the deployment box may lack."""
+    try:
+        import h5py
+        opener = lambda p: h5py.File(p, "r")       # noqa: E731
+    except ImportError:
+        from . import h5lite
+        opener = h5lite.File
+    with opener(path) as f:
+        return from_keras_h5(f, d)
+
+
+def load_any(path, d):
+    """.npz of this package, or a Keras .h5 checkpoint (recognised by the file signature, not the extension)."""
+    from . import h5lite
+    return load_keras_h5(path, d) if h5lite.is_hdf5(path) else load_npz(path)

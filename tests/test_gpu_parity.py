@@ -307,6 +307,28 @@ def test_fused_detect_matches_oracle_end_to_end(pp, engines, name):
     _assert_dets(got, ref["dets"])
 
 
+def test_keras_h5_checkpoint_into_the_engine(pp, hip_lib):
+    """f4 end to end (train.py:731-734, net.load_weights(model_weights_<epoch>.h5)): the checkpoint file written by the
+    real HDF5 library in Keras's layout (tests/golden/keras_ckpt_tiny.h5, tools/gen_golden_h5.py) goes straight into
+    VoxelNet.load_weights; the detections match the oracle run on the weights the file was made from."""
+    import os
+    B = 2
+    cfg = pp.config.tiny_config(B)
+    net = pp.VoxelNet(cfg, None, training=False, max_batch=B)
+    try:
+        net.load_weights(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keras_ckpt_tiny.h5"))
+        w = pp.weights.init_weights(net.d, seed=29)
+        rng = np.random.default_rng(23)
+        frames = [rng.uniform([0, -0.64, -3], [1.6, 0.64, 3], (n, 3)).astype(np.float32) for n in (900, 450)]
+        rect, trv, p2 = pp.synth.default_calib()
+        ref = util_ref.oracle_detect(net.d, w, frames, rect, trv, p2)
+        got = net.detect(frames, np.stack([rect] * B), np.stack([trv] * B))
+        _assert_dets(got, ref["dets"])
+        assert any(r["scores"] is not None for r in ref["dets"])
+    finally:
+        net.engine.close()
+
+
 # ------------------------------------------------------------------ size-independent properties at full batch
 def test_full_batch_properties(pp, engines):
     B = 64

@@ -144,48 +144,16 @@ class _FakeGroup(dict):
 
 
 def _fake_keras_checkpoint(pp, d, w):
-    """The variable list Keras 2.3 / TF 2.2 writes for the reference's model tree: anonymous layers numbered by
-    creation order, per top-level layer the trainable variables in layer order, then the moving statistics."""
+    """The variable list Keras 2.3 / TF 2.2 writes for the reference's model tree (tests/keras_tree.py) as a dict tree."""
+    from keras_tree import LAYER_NAMES, keras_variables
     root = _FakeGroup()
-    root.attrs["layer_names"] = [b"weighted_smooth_l1_localization_loss", b"pillar_feature_net", b"point_pillars_scatter", b"rpn"]
-    root["weighted_smooth_l1_localization_loss"] = _FakeGroup()
-    root["point_pillars_scatter"] = _FakeGroup()
-    pfn = _FakeGroup()
-    pn = "voxel_net/pillar_feature_net/sequential/"
-    pairs = [(pn + "dense/kernel:0", "pfn/dense/kernel"), (pn + "batch/gamma:0", "pfn/bn/gamma"), (pn + "batch/beta:0", "pfn/bn/beta"),
-             (pn + "batch/moving_mean:0", "pfn/bn/moving_mean"), (pn + "batch/moving_variance:0", "pfn/bn/moving_variance")]
-    pfn.attrs["weight_names"] = [k.encode() for k, _ in pairs]
-    for k, ours in pairs:
-        pfn[k] = w[ours]
-    root["pillar_feature_net"] = pfn
-    rpn = _FakeGroup()
-    train, moving = [], []
-    n_sep = n_bn = n_dec = 0
-
-    def suffix(n):
-        return "" if n == 0 else f"_{n}"
-    for b in range(3):
-        for j in range(d.layer_nums[b] + 1):
-            base, ours = f"voxel_net/rpn/block{b + 1}/", f"rpn/block{b + 1}/{j}"
-            sep, bn = f"separable_conv2d{suffix(n_sep)}", f"batch_normalization{suffix(n_bn)}"
-            n_sep += 1
-            n_bn += 1
-            train += [(base + sep + "/depthwise_kernel:0", ours + "/depthwise_kernel"), (base + sep + "/pointwise_kernel:0", ours + "/pointwise_kernel"),
-                      (base + bn + "/gamma:0", ours + "/bn/gamma"), (base + bn + "/beta:0", ours + "/bn/beta")]
-            moving += [(base + bn + "/moving_mean:0", ours + "/bn/moving_mean"), (base + bn + "/moving_variance:0", ours + "/bn/moving_variance")]
-        # the reference builds deconv{b} right after block{b}; Keras lists RPN.layers in attribute order
-        base, ours = f"voxel_net/rpn/deconv{b + 1}/", f"rpn/deconv{b + 1}"
-        dec, bn = f"conv2d_transpose{suffix(n_dec)}", f"batch_normalization{suffix(n_bn)}"
-        n_dec += 1
-        n_bn += 1
-        train += [(base + dec + "/kernel:0", ours + "/kernel"), (base + bn + "/gamma:0", ours + "/bn/gamma"), (base + bn + "/beta:0", ours + "/bn/beta")]
-        moving += [(base + bn + "/moving_mean:0", ours + "/bn/moving_mean"), (base + bn + "/moving_variance:0", ours + "/bn/moving_variance")]
-    for hname in ("conv_box", "conv_cls", "conv_dir_cls"):
-        train += [(f"voxel_net/rpn/{hname}/kernel:0", f"rpn/{hname}/kernel"), (f"voxel_net/rpn/{hname}/bias:0", f"rpn/{hname}/bias")]
-    rpn.attrs["weight_names"] = [k.encode() for k, _ in train + moving]
-    for k, ours in train + moving:
-        rpn[k] = w[ours]
-    root["rpn"] = rpn
+    root.attrs["layer_names"] = [n.encode() for n in LAYER_NAMES]
+    for layer, variables in keras_variables(d).items():
+        g = _FakeGroup()
+        g.attrs["weight_names"] = [k.encode() for k, _ in variables]
+        for k, ours in variables:
+            g[k] = w[ours] if ours is not None else np.ones(7, np.float32)
+        root[layer] = g
     return root
 
 

@@ -4,8 +4,9 @@ train.py:407,436 and read back by net.load_weights at train.py:731-734) into the
 
     python tools/h5_to_npz.py configs/train.yaml out/model_345/out_dir_checkpoints/model_weights_48.h5 weights_48.npz
 
-Needs h5py (not installed in the build image: run it wherever the checkpoint lives).  The name mapping and its
-checks are `weights.map_keras_weight_names` / `weights.from_keras_h5` (unit-tested with a synthetic group tree)."""
+h5py is used when installed; otherwise the package's own reader (h5lite.py).  The name mapping and its checks are
+`weights.map_keras_weight_names` / `weights.from_keras_h5` (tests/test_h5lite.py reads a checkpoint written by the real
+HDF5 library in Keras's layout; `VoxelNet.load_weights(path)` takes the .h5 directly as well)."""
 import os
 import sys
 
@@ -17,14 +18,8 @@ def main(argv):
     if len(argv) != 4:
         print(__doc__)
         return 2
-    try:
-        import h5py
-    except ImportError:
-        print("h5py is required to read the checkpoint (pip install h5py)")
-        return 1
     d = pp_amd.config.Derived(pp_amd.config.load_yaml(argv[1]))
-    with h5py.File(argv[2], "r") as f:
-        w = pp_amd.weights.from_keras_h5(f, d)
+    w = pp_amd.weights.load_keras_h5(argv[2], d)
     pp_amd.weights.save_npz(argv[3], w)
     print(f"{len(w)} tensors, {sum(v.size for v in w.values())} parameters -> {argv[3]}")
     return 0
