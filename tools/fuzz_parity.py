@@ -1,0 +1,164 @@
+"""Randomised whole-path parity soak on the GPU box: configurations, batch sizes and clouds the tests do not pin.
+
+    python tools/fuzz_parity.py [--seconds 300] [--seed0 1000] [--out gpurun_out/fuzz.log]
+
+Per case: a random reference-schema configuration (grid, first stride, z cells, point features, channel widths, layer
+counts, class count, direction head, distance feature, pillar caps, NMS sizes and thresholds), a random batch size from
+both sides of the engine's kernel selection (a handful of frames: the split-K small-map kernels; dozens: the
+persistent ones), random clouds (empty frames, points outside the range, crowded pillars).  The HIP path through the
+C-ABI is compared with the oracle exactly as tests/test_gpu_parity.py::test_random_small_configs_end_to_end does
+(pillars / anchor mask bit-exact, head maps and boxes within 1e-4).  TEST INFRASTRUCTURE: imports oracle/.
+Prints one line per case and a summary; exit code 1 on any mismatch (the failing seed reproduces the case).
+"""
+import argparse
+import copy
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+TOL = 1e-4
+
+
+def random_config(pp, rng, B):
+    cfg = copy.deepcopy(pp.config.pedestrian_d435i_config(B))
+    s1 = int(rng.choice([1, 2]))
+    nx, ny = 4 * s1 * int(rng.integers(3, 14)), 4 * s1 * int(rng.integers(2, 12))
+    v = float(rng.choice([0.08, 0.16]))
+    nz2 = bool(rng.integers(0, 2))
+    zr = (-3.0, 3.0) if nz2 else (-3.0, 1.0)
+    x0, y0 = 0.0, -ny * v / 2
+    F = int(rng.choice([3, 4]))
+    C = int(rng.choice([32, 64, 128]))
+    filters = [int(rng.choice([32, 64, 128])), int(rng.choice([32, 64, 128])), int(rng.choice([64, 128, 256]))]
+    up = int(rng.choice([32, 64, 128]))
+    ncls = int(rng.choice([1, 1, 2, 3]))
+    cfg["eval_input_reader"].update(batch_size=B, feature_map_size=[1, ny // s1, nx // s1], num_point_features=F)
+    if ncls > 1:
+        cfg["eval_input_reader"]["desired_objects"] = ["Pedestrian", "Cyclist", "Car"][:ncls]
+    s = cfg["model"]["second"]
+    s["num_point_features"] = F
+    s["num_class"] = ncls
+    s["use_direction_classifier"] = bool(rng.integers(0, 4) > 0)
+    s["voxel_generator"].update(point_cloud_range=[x0, y0, zr[0], x0 + nx * v, y0 + ny * v, zr[1]],
+                                max_number_of_points_per_voxel=int(rng.choice([5, 12, 50, 100])),
+                                max_number_of_voxels=int(rng.choice([150, 2000, 12000])))
+    s["voxel_feature_extractor"]["num_filters"] = C
+    s["voxel_feature_extractor"]["with_distance"] = bool(rng.integers(0, 3) == 0)
+    s["rpn"].update(layer_nums=[int(rng.integers(1, 4)) for _ in range(3)], layer_strides=[s1, 2, 2],
+                    num_filters=filters, upsample_strides=[1, 2, 4], num_upsample_filters=[up] * 3)
+    s["target_assigner"]["anchor_generators"]["anchor_generator_stride"].update(
+        strides=[v * s1, v * s1, 0.0], offsets=[x0 + v * s1, y0, -1.465])
+    s["nms_pre_max_size"] = int(rng.choice([50, 300, 1000]))
+    s["nms_post_max_size"] = int(rng.choice([5, 100, 300]))
+    s["nms_score_threshold"] = float(rng.choice([0.05, 0.3, 0.5]))
+    s["nms_iou_threshold"] = float(rng.choice([0.1, 0.5, 0.7]))
+    return cfg
+
+
+def random_frames(rng, d, B):
+    lo, hi = np.array(d.pc_range[:3]), np.array(d.pc_range[3:])
+    frames = []
+    for b in range(B):
+        kind = int(rng.integers(0, 8))
+        n = 0 if kind == 0 else int(rng.integers(1, 60)) if kind == 1 else int(rng.integers(300, 6000))
+        xyz = rng.uniform(lo - 0.2, hi + 0.2, (n, 3))
+        if kind == 2 and n:                      # a crowd in a few pillars
+            c = rng.uniform(lo, hi, (4, 3))
+            xyz[: n // 2] = c[rng.integers(0, 4, n // 2)] + rng.uniform(-0.03, 0.03, (n // 2, 3))
+        extra = rng.uniform(0, 1, (n, d.num_point_features - 3))
+        frames.append(np.concatenate([xyz, extra], axis=1).astype(np.float32))
+    return frames
+
+
+def one_case(pp, util_ref, seed):
+    rng = np.random.default_rng(seed)
+    B = int(rng.choice([1, 2, 3, 5, 8, 17, 32]))
+    cfg = random_config(pp, rng, B)
+    eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=8192)
+    try:
+        d = eng.d
+        w = pp.weights.init_weights(d, seed=seed)
+        eng.load_weights(w)
+        frames = random_frames(rng, d, B)
+        rect, trv, p2 = pp.synth.default_calib()
+        ref = util_ref.oracle_detect(d, w, frames, rect, trv, p2)
+        dets, n = eng.detect(frames, np.stack([rect] * B), np.stack([trv] * B))
+        im = eng.intermediates()
+        for b in range(B):
+            fr = ref["frames"][b]
+            P = fr["coordinates"].shape[0]
+            assert im["n_pillars"][b] == P, f"frame {b}: {im['n_pillars'][b]} pillars, oracle {P}"
+            assert np.array_equal(im["coors"][b, :P], fr["coordinates"]), f"frame {b}: coordinates"
+            assert np.array_equal(im["num_points"][b, :P], fr["num_points"]), f"frame {b}: num_points"
+            assert np.array_equal(im["anchors_mask"][b].astype(bool), fr["anchors_mask"]), f"frame {b}: anchor mask"
+        worst = 0.0
+        for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+            if ref["preds"].get(k) is None:
+                continue
+            err = float(np.max(np.abs(im[k] - ref["preds"][k]))) if im[k].size else 0.0
+            worst = max(worst, err)
+            assert err <= TOL, f"{k}: max abs err {err:.3g}"
+        ndet = 0
+        for b in range(B):
+            a = pp.VoxelNet._to_dict(dets[b], int(n[b]), b)
+            r = ref["dets"][b]
+            if r["scores"] is None:
+                assert a["scores"] is None, f"frame {b}: {int(n[b])} detections, oracle none"
+                continue
+            assert a["scores"] is not None and a["scores"].shape == r["scores"].shape, \
+                f"frame {b}: {int(n[b])} detections, oracle {r['scores'].shape[0]}"
+            ndet += r["scores"].shape[0]
+            np.testing.assert_allclose(a["scores"], r["scores"], rtol=0, atol=TOL)
+            np.testing.assert_allclose(a["box3d_lidar"], r["box3d_lidar"], rtol=0, atol=TOL)
+            np.testing.assert_allclose(a["box3d_camera"], r["box3d_camera"], rtol=0, atol=TOL)
+            assert np.array_equal(a["label_preds"], r["label_preds"]), f"frame {b}: labels"
+        return f"B={B} grid={d.grid[0]}x{d.grid[1]}x{d.grid[2]} C={d.pfn_filters} f={d.num_filters} L={d.layer_nums} " \
+               f"cls={d.num_class} dir={int(d.use_direction_classifier)} dets={ndet} maxerr={worst:.2e}"
+    finally:
+        eng.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed0", type=int, default=1000)
+    ap.add_argument("--max-cases", type=int, default=100000)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    import pp_amd as pp
+    import util_ref
+    pp._lib.build()
+    pp._lib.lib()
+    out = open(a.out, "w") if a.out else None
+
+    def say(line):
+        print(line, flush=True)
+        if out:
+            out.write(line + "\n")
+            out.flush()
+    t0, seed, bad, n = time.time(), a.seed0, [], 0
+    while time.time() - t0 < a.seconds and n < a.max_cases:
+        try:
+            say(f"seed {seed}: ok  {one_case(pp, util_ref, seed)}")
+        except AssertionError as ex:
+            bad.append(seed)
+            say(f"seed {seed}: MISMATCH {str(ex)[:300]}")
+        except Exception as ex:  # noqa: BLE001
+            bad.append(seed)
+            say(f"seed {seed}: ERROR {type(ex).__name__}: {str(ex)[:300]}")
+            say(traceback.format_exc()[-1500:])
+        seed += 1
+        n += 1
+    say(f"{n} cases in {time.time() - t0:.0f} s, {len(bad)} bad: {bad}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
