@@ -7,7 +7,8 @@ counts, class count, direction head, distance feature, pillar caps, NMS sizes an
 both sides of the engine's kernel selection (a handful of frames: the split-K small-map kernels; dozens: the
 persistent ones), random clouds (empty frames, points outside the range, crowded pillars).  The HIP path through the
 C-ABI is compared with the oracle exactly as tests/test_gpu_parity.py::test_random_small_configs_end_to_end does
-(pillars / anchor mask bit-exact, head maps and boxes within 1e-4).  TEST INFRASTRUCTURE: imports oracle/.
+(pillars / anchor mask bit-exact, head maps within 1e-4, boxes within 1e-4 + 1e-5 of their size; rows that
+changed places must share their score: the reference's order of equal scores is implementation-defined).  TEST INFRASTRUCTURE: imports oracle/.
 Prints one line per case and a summary; exit code 1 on any mismatch (the failing seed reproduces the case).
 """
 import argparse
@@ -47,7 +48,7 @@ def random_config(pp, rng, B):
     s["num_class"] = ncls
     s["use_direction_classifier"] = bool(rng.integers(0, 4) > 0)
     s["voxel_generator"].update(point_cloud_range=[x0, y0, zr[0], x0 + nx * v, y0 + ny * v, zr[1]],
-                                max_number_of_points_per_voxel=int(rng.choice([5, 12, 50, 100])),
+                                voxel_size=[v, v, 4.0], max_number_of_points_per_voxel=int(rng.choice([5, 12, 50, 100])),
                                 max_number_of_voxels=int(rng.choice([150, 2000, 12000])))
     s["voxel_feature_extractor"]["num_filters"] = C
     s["voxel_feature_extractor"]["with_distance"] = bool(rng.integers(0, 3) == 0)
@@ -105,7 +106,7 @@ def one_case(pp, util_ref, seed):
             err = float(np.max(np.abs(im[k] - ref["preds"][k]))) if im[k].size else 0.0
             worst = max(worst, err)
             assert err <= TOL, f"{k}: max abs err {err:.3g}"
-        ndet = 0
+        ndet, ties = 0, 0
         for b in range(B):
             a = pp.VoxelNet._to_dict(dets[b], int(n[b]), b)
             r = ref["dets"][b]
@@ -114,13 +115,34 @@ def one_case(pp, util_ref, seed):
                 continue
             assert a["scores"] is not None and a["scores"].shape == r["scores"].shape, \
                 f"frame {b}: {int(n[b])} detections, oracle {r['scores'].shape[0]}"
-            ndet += r["scores"].shape[0]
-            np.testing.assert_allclose(a["scores"], r["scores"], rtol=0, atol=TOL)
-            np.testing.assert_allclose(a["box3d_lidar"], r["box3d_lidar"], rtol=0, atol=TOL)
-            np.testing.assert_allclose(a["box3d_camera"], r["box3d_camera"], rtol=0, atol=TOL)
-            assert np.array_equal(a["label_preds"], r["label_preds"]), f"frame {b}: labels"
+            k = r["scores"].shape[0]
+            ndet += k
+            rows_a = np.concatenate([a["box3d_lidar"], a["box3d_camera"], a["scores"][:, None], a["label_preds"][:, None]], axis=1)
+            rows_r = np.concatenate([r["box3d_lidar"], r["box3d_camera"], r["scores"][:, None], r["label_preds"][:, None]], axis=1)
+            # decoded sizes are exp(t) * anchor: with random weights a box can be 50 m long and carry the head map's 1e-6
+            # relative error as 1e-4 absolute -- rows are compared to 1e-4 + 1e-5 * |oracle| (in units of that bound)
+            scale = lambda ref_rows: TOL + 1e-5 * np.abs(ref_rows)      # noqa: E731
+            if np.max(np.abs(rows_a - rows_r) / scale(rows_r)) <= 1.0:
+                continue
+            # Not the same rows in the same order.  The one accepted reason (deviation 2): the order of
+            # EQUAL scores is implementation-defined in the reference (np.argpartition / argsort) -- the same boxes must
+            # then be there, and a box may only have moved past boxes whose score it shares to within twice this case's
+            # measured head-map error (a logit error e moves a score by at most e / 4).
+            dist = np.max(np.abs(rows_a[:, None, :] - rows_r[None, :, :]) / scale(rows_r)[None, :, :], axis=2) * TOL
+            perm = np.argmin(dist, axis=1)
+            if not (sorted(perm.tolist()) == list(range(k)) and np.all(dist[np.arange(k), perm] <= TOL)):
+                i = int(np.argmax(np.min(dist, axis=1)))
+                raise AssertionError(f"frame {b}: different boxes (worst row distance {float(np.max(np.min(dist, axis=1))):.3g}; "
+                                     f"row {i}: hip {np.array2string(rows_a[i], precision=6)} oracle "
+                                     f"{np.array2string(rows_r[perm[i]], precision=6)})")
+            sc = r["scores"]
+            for i in range(k):
+                lo_, hi_ = min(i, perm[i]), max(i, perm[i])
+                assert float(np.max(sc[lo_:hi_ + 1]) - np.min(sc[lo_:hi_ + 1])) <= max(2e-6, 2 * worst), \
+                    f"frame {b}: box {i} moved to {perm[i]} across scores {sc[lo_:hi_ + 1]}"
+            ties += 1
         return f"B={B} grid={d.grid[0]}x{d.grid[1]}x{d.grid[2]} C={d.pfn_filters} f={d.num_filters} L={d.layer_nums} " \
-               f"cls={d.num_class} dir={int(d.use_direction_classifier)} dets={ndet} maxerr={worst:.2e}"
+               f"cls={d.num_class} dir={int(d.use_direction_classifier)} dets={ndet} maxerr={worst:.2e}" + (f" tie-order-frames={ties}" if ties else "")
     finally:
         eng.close()
 
@@ -131,6 +153,7 @@ def main():
     ap.add_argument("--seed0", type=int, default=1000)
     ap.add_argument("--max-cases", type=int, default=100000)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--seeds", default=None, help="comma-separated seeds to run instead of the timed sweep")
     a = ap.parse_args()
     import pp_amd as pp
     import util_ref
@@ -144,12 +167,15 @@ def main():
             out.write(line + "\n")
             out.flush()
     t0, seed, bad, n = time.time(), a.seed0, [], 0
-    while time.time() - t0 < a.seconds and n < a.max_cases:
+    todo = [int(v) for v in a.seeds.split(",")] if a.seeds else None
+    while (todo is None and time.time() - t0 < a.seconds and n < a.max_cases) or (todo is not None and n < len(todo)):
+        if todo is not None:
+            seed = todo[n]
         try:
             say(f"seed {seed}: ok  {one_case(pp, util_ref, seed)}")
         except AssertionError as ex:
             bad.append(seed)
-            say(f"seed {seed}: MISMATCH {str(ex)[:300]}")
+            say(f"seed {seed}: MISMATCH " + " ".join(str(ex).split())[:900])
         except Exception as ex:  # noqa: BLE001
             bad.append(seed)
             say(f"seed {seed}: ERROR {type(ex).__name__}: {str(ex)[:300]}")
