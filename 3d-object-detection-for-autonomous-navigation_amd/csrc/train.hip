@@ -443,8 +443,21 @@ __global__ __launch_bounds__(256) void k_tr_reduce_cols(const float* __restrict_
     const int l = threadIdx.x & 63;
     const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     float s = 0.f;
-    if (i < n)
-        for (int p = l; p < nparts; p += 64) s += part[(size_t)p * pstride + i];
+    if (i < n) {
+        int p = l;
+        for (; p + 64 * 7 < nparts; p += 64 * 8) {          // eight rows' loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(p + 64 * k) * pstride + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (p + 64 * k < nparts) ? part[(size_t)(p + 64 * k) * pstride + i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if (i >= n || l != 0) return;
@@ -463,7 +476,21 @@ __global__ __launch_bounds__(256) void k_tr_reduce_cols_wg(const float* __restri
     __shared__ float sw[4];
     const long i = blockIdx.x;
     float s = 0.f;
-    for (int p = threadIdx.x; p < nparts; p += 256) s += part[(size_t)p * pstride + i];
+    {
+        int p = threadIdx.x;
+        for (; p + 256 * 3 < nparts; p += 256 * 4) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = part[(size_t)(p + 256 * k) * pstride + i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += v[k];
+        }
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (p + 256 * k < nparts) ? part[(size_t)(p + 256 * k) * pstride + i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += v[k];
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
@@ -1074,12 +1101,28 @@ __global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict_
     const int c = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
     float s1 = 0.f, s2 = 0.f;
     if (c < C) {
+        // lane l adds the (partial row, tap) pairs l, l + LPC, ... in that order, EIGHT pairs' loads in flight at a time:
+        // written as "load, add, load, add" the loop waited a full memory round trip per pair (the disassembly had a
+        // vmcnt(0) per iteration) and this launch -- 20 per step -- took 5.6 us at B=2 / 9 us at B=32 for ~2 us of work
         const size_t N = (size_t)C * ntaps;
-        for (int p = l; p < nparts; p += LPC)
-            for (int t = 0; t < ntaps; ++t) {
-                s1 += part[((size_t)p * 2 + 0) * N + (size_t)t * C + c];
-                s2 += part[((size_t)p * 2 + 1) * N + (size_t)t * C + c];
+        const int total = nparts * ntaps;
+        for (int i0 = l; i0 < total; i0 += LPC * 8) {
+            float a[8], q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * LPC;
+                const bool ok = i < total;
+                const int ic = ok ? i : l;                         // (a valid pair; its value is dropped below)
+                int pr = ic, t = 0;
+                if (ntaps > 1) { pr = ic / ntaps; t = ic - pr * ntaps; }      // (uniform: only the transposed convolutions)
+                const float* src = part + ((size_t)pr * 2) * N + (size_t)t * C + c;
+                a[k] = src[0];
+                q[k] = src[N];
+                if (!ok) { a[k] = 0.f; q[k] = 0.f; }
             }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s1 += a[k]; s2 += q[k]; }
+        }
     }
 #pragma unroll
     for (int off = (LPC > 64 ? 64 : LPC) / 2; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }

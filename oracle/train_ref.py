@@ -30,11 +30,15 @@ def _bn_train(x, gamma, beta, dims):
     return (x - mean) / torch.sqrt(var + BN_EPS) * gamma.reshape(shape) + beta.reshape(shape), mean.flatten(), var.flatten()
 
 
-def training_step(d, w, example, labels, reg_targets, anchors, num_threads=None, dtype=torch.float32):
+def training_step(d, w, example, labels, reg_targets, anchors, num_threads=None, dtype=torch.float32, margins=None):
     """d: config.Derived; w: Keras-layout dict of numpy arrays; example: the oracle's merged batch (padded voxels,
     num_points, coors[b,z,y,x], ...).  Returns (loss dict of floats, gradient dict name -> numpy for every trainable
     tensor, batch statistics dict name -> (mean, biased var)).  dtype=torch.float64: the same graph in double
-    precision (the yardstick that tells float32 round-off of the restatement apart from an error of the kernels)."""
+    precision (the yardstick that tells float32 round-off of the restatement apart from an error of the kernels).
+    margins: a dict that receives, per BatchNorm + ReLU layer, the smallest |pre-ReLU value| of the step (and for the PFN
+    the smallest positive gap between a pillar's largest and second-largest row): ReLU and max are not differentiable
+    there, so an implementation whose round-off puts such an element on the other side returns a gradient that differs
+    by that element's whole contribution -- a property of the problem, not an error (tools/fuzz_train.py uses it)."""
     if num_threads:
         torch.set_num_threads(num_threads)
     voxels, num_points, coors = example[0], example[1], example[2]
@@ -48,6 +52,12 @@ def training_step(d, w, example, labels, reg_targets, anchors, num_threads=None,
     yn, m, v = _bn_train(y, t["pfn/bn/gamma"], t["pfn/bn/beta"], (0, 1))
     stats["pfn/bn"] = (m.detach().numpy(), v.detach().numpy())
     f = torch.relu(yn).amax(dim=1)                                      # [P, C]
+    if margins is not None:
+        with torch.no_grad():
+            top = torch.topk(torch.relu(yn), 2, dim=1).values if yn.shape[1] > 1 else None
+            gap = (top[:, 0] - top[:, 1]) if top is not None else None
+            win = yn.amax(dim=1)                                           # the winning row's pre-ReLU value
+            margins["pfn/bn"] = float(min(win.abs().min(), gap[gap > 0].min() if gap is not None and bool((gap > 0).any()) else 1.0))
     idx = torch.from_numpy((coors[:, 0].astype(np.int64) * d.ny + coors[:, 2]) * d.nx + coors[:, 3])
     canvas = torch.zeros(B * d.ny * d.nx, f.shape[1], dtype=dtype).index_add(0, idx, f).reshape(B, d.ny, d.nx, -1)
     x = canvas.permute(0, 3, 1, 2)
@@ -63,12 +73,16 @@ def training_step(d, w, example, labels, reg_targets, anchors, num_threads=None,
             x = Fn.conv2d(x, pw)
             x, m, v = _bn_train(x, t[pre + "/bn/gamma"], t[pre + "/bn/beta"], (0, 2, 3))
             stats[pre + "/bn"] = (m.detach().numpy(), v.detach().numpy())
+            if margins is not None:
+                margins[pre + "/bn"] = float(x.detach().abs().min())
             x = torch.relu(x)
         pre = f"rpn/deconv{b + 1}"
         k = d.upsample_strides[b]
         u = Fn.conv_transpose2d(x, t[pre + "/kernel"].permute(3, 2, 0, 1), stride=k)   # [k,k,Cout,Cin] -> [Cin,Cout,k,k]
         u, m, v = _bn_train(u, t[pre + "/bn/gamma"], t[pre + "/bn/beta"], (0, 2, 3))
         stats[pre + "/bn"] = (m.detach().numpy(), v.detach().numpy())
+        if margins is not None:
+            margins[pre + "/bn"] = float(u.detach().abs().min())
         ups.append(torch.relu(u))
     cat = torch.cat(ups, dim=1)
 

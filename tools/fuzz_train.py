@@ -24,6 +24,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+VERBOSE = False
+
+
 def one_case(pp, util_ref, train_ref, fuzz_parity, seed):
     rng = np.random.default_rng(seed)
     B = int(rng.integers(1, 7))
@@ -35,6 +38,7 @@ def one_case(pp, util_ref, train_ref, fuzz_parity, seed):
     v = 0.08
     zr = s["voxel_generator"]["point_cloud_range"][2::3]
     s["voxel_generator"]["point_cloud_range"] = [0.0, -ny * v / 2, zr[0], nx * v, ny * v / 2, zr[1]]
+    s["voxel_generator"]["voxel_size"] = [v, v, 4.0]
     cfg["eval_input_reader"]["feature_map_size"] = [1, ny // s1, nx // s1]
     s["target_assigner"]["anchor_generators"]["anchor_generator_stride"].update(
         strides=[v * s1, v * s1, 0.0], offsets=[v * s1, -ny * v / 2, -1.465])
@@ -65,26 +69,75 @@ def one_case(pp, util_ref, train_ref, fuzz_parity, seed):
         for k in ("loss", "loc_loss_reduced", "cls_loss_reduced", "dir_loss_reduced"):
             assert abs(out[k] - vals[k]) <= 2e-5 * max(1.0, abs(vals[k])), (k, out[k], vals[k])
         assert out["num_positives"] == vals["num_positives"]
+        # forward probe per BatchNorm layer: the batch mean / variance the step folded into the moving statistics
+        after = tr.weights()
+        fwd_worst = ("", 0.0)
+        for pre, (mean, var) in stats.items():
+            mom = 0.01 if pre == "pfn/bn" else 0.99
+            got_mean = (after[pre + "/moving_mean"] - w[pre + "/moving_mean"] * mom) / (1 - mom)
+            em = float(np.max(np.abs(got_mean - mean))) / max(float(np.max(np.abs(mean))), 1e-6)
+            if VERBOSE:
+                print(f"    fwd {pre:36s} batch-mean rel err {em:.2e}", flush=True)
+            if em > fwd_worst[1]:
+                fwd_worst = (pre, em)
         got = tr.gradients()
         worst = ("", 0.0)
         for name, g in grads.items():
             assert got[name].shape == g.shape, name
             e = float(np.abs(got[name] - g).max()) / max(float(np.abs(g).max()), 1e-12)
+            if VERBOSE:
+                print(f"    {name:40s} {str(g.shape):20s} max|g| {float(np.abs(g).max()):.3e}  rel err {e:.2e}", flush=True)
             if e > worst[1]:
                 worst = (name, e)
         out2 = tr.forward_backward(frames, labels, reg)
         assert out2["loss"] == out["loss"] and np.array_equal(tr.grads.cpu().numpy(), g1), "second pass differs"
         desc = (f"B={B} grid={d.nx}x{d.ny}x{d.nz} s1={s1} C={d.pfn_filters} f={d.num_filters} L={d.layer_nums} cls={d.num_class} "
-                f"dir={int(d.use_direction_classifier)} dist={int(d.with_distance)} T={d.max_points} worst={worst[1]:.2e} ({worst[0]})")
+                f"dir={int(d.use_direction_classifier)} dist={int(d.with_distance)} T={d.max_points} worst={worst[1]:.2e} ({worst[0]}) "
+                f"fwd={fwd_worst[1]:.1e} ({fwd_worst[0]})")
         if worst[1] > 1e-4:
-            # float32 round-off of the problem itself?  the same graph in float64 is the yardstick: the kernels may be as
-            # far from it as torch's own float32 autograd is (x3), as tests/test_gpu_train.py holds the shipped shape
-            _, g64, _, _ = train_ref.training_step(d, w, ex, labels, reg, ex[6][0], dtype=__import__("torch").float64)
+            # The same graph in float64 is the yardstick.  Two legitimate reasons for a float32 implementation to be off:
+            # (1) the problem's float32 conditioning (torch's own float32 autograd is then as far from float64): the kernels
+            # may be x3 of that, as tests/test_gpu_train.py holds the shipped shape; (2) an element within round-off of a
+            # ReLU's kink or of a tie of the PFN's max (`margins` of the float64 run): whichever side an implementation's
+            # round-off puts it, the gradient changes by that element's whole contribution -- on these small maps 1e-3 ..
+            # 1e-1 of a tensor's gradient.  Such a case is reported as "ambiguous", not as a mismatch.
+            marg = {}
+            _, g64, _, _ = train_ref.training_step(d, w, ex, labels, reg, ex[6][0], dtype=__import__("torch").float64, margins=marg)
             def err(a, b):
                 return max(float(np.abs(a[k] - b[k]).max()) / max(float(np.abs(b[k]).max()), 1e-12) for k in b)
             ek, et = err(got, g64), err(grads, g64)
-            desc += f" | vs float64: kernels {ek:.2e}, torch float32 {et:.2e}"
-            assert ek <= 3 * et, desc
+            mlayer = min(marg, key=marg.get)
+            desc += f" | vs float64: kernels {ek:.2e}, torch float32 {et:.2e}; smallest ReLU / max margin {marg[mlayer]:.1e} ({mlayer})"
+            if ek > 3 * et:
+                # ... and only the layers in FRONT of such an element (its own parameters included) may be affected: every
+                # tensor that does not lie on a path into one of the near-kink layers must still meet the bar
+                def order(layer):           # (block, position): pfn (0, 0); block b layer j (b, 1 + j); deconv b (b, 99)
+                    if layer.startswith("pfn"):
+                        return (0, 0)
+                    parts = layer.split("/")
+                    if parts[1].startswith("block"):
+                        return (int(parts[1][5:]), 1 + int(parts[2]))
+                    if parts[1].startswith("deconv"):
+                        return (int(parts[1][6:]), 99)
+                    return (9, 0)           # heads: nothing behind them has a kink
+                kinks = [order(k[:-3]) for k, v in marg.items() if v < 4e-6]
+                def may_differ(name):
+                    o = order(name)
+                    if o == (9, 0):
+                        return False
+                    for kb, kp in kinks:
+                        if o[1] == 99:                       # a transposed convolution: only its own kink
+                            if (kb, kp) == o:
+                                return True
+                        elif o[0] < kb or (o[0] == kb and o[1] <= kp):
+                            return True
+                    return False
+                outside = [(k, float(np.abs(got[k] - g64[k]).max()) / max(float(np.abs(g64[k]).max()), 1e-12)) for k in g64
+                           if not may_differ(k)]
+                bad_out = [(k, e) for k, e in outside if e > max(1e-4, 3 * et)]
+                if kinks and not bad_out:
+                    return "AMBIGUOUS " + desc
+                raise AssertionError(desc + (f" | outside the kinks' cones: {bad_out[:3]}" if kinks else ""))
         return desc
     finally:
         tr.close()
@@ -95,7 +148,11 @@ def main():
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed0", type=int, default=5000)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--seeds", default=None, help="comma-separated seeds to run instead of the timed sweep")
+    ap.add_argument("--verbose", action="store_true", help="per-tensor errors")
     a = ap.parse_args()
+    global VERBOSE
+    VERBOSE = a.verbose
     import pp_amd as pp
     import util_ref
     from oracle import train_ref
@@ -110,9 +167,13 @@ def main():
             out.write(line + "\n")
             out.flush()
     t0, seed, bad, n = time.time(), a.seed0, [], 0
-    while time.time() - t0 < a.seconds:
+    todo = [int(v) for v in a.seeds.split(",")] if a.seeds else None
+    while (todo is None and time.time() - t0 < a.seconds) or (todo is not None and n < len(todo)):
+        if todo is not None:
+            seed = todo[n]
         try:
-            say(f"seed {seed}: ok  {one_case(pp, util_ref, train_ref, fuzz_parity, seed)}")
+            res = one_case(pp, util_ref, train_ref, fuzz_parity, seed)
+            say(f"seed {seed}: " + (res if res.startswith("AMBIGUOUS") else "ok  " + res))
         except AssertionError as ex:
             bad.append(seed)
             say(f"seed {seed}: MISMATCH {str(ex)[:400]}")
