@@ -7,6 +7,7 @@
 * the asynchronous entry points and the handle's state rules (graph eviction under load, weight reloads,
   device-resident input, stage calls invalidating the fused state).
 """
+import os
 import numpy as np
 import pytest
 
@@ -799,3 +800,37 @@ def test_float32_fallback_on_the_sparse_canvas_configuration(pp, hip_lib):
     dets2, n2 = eng.detect(frames, R, T)
     assert np.array_equal(n2, n) and dets2.tobytes() == dets.tobytes(), "back on the split path: the same bits as before"
     eng.close()
+
+
+# ------------------------------------------------------------------ randomised soaks (tools/fuzz_parity.py, tools/fuzz_train.py)
+def _tool(name):
+    import importlib
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    return importlib.import_module(name)
+
+
+@pytest.mark.parametrize("seed", [1081, 1304, 10012, 10026, 10758, 10900, 10901, 10902])
+def test_fuzz_parity_seeds(pp, hip_lib, seed):
+    """A few cases of the randomised whole-path soak (round 4: 1 128 + 1 693 valid cases on the GPU box, none outside the
+    bars): random grids / strides / widths / classes / NMS settings / batch sizes 1..32.  Seeds 1081 and 1304 hold two
+    boxes whose scores agree to 1e-7 (the reference's order of equal scores is implementation-defined: the soak
+    accepts a swap among equal scores and nothing else), 10758 a 32 m box (sizes are exp(t) * anchor: compared to 1e-4
+    + 1e-5 of their size)."""
+    fz = _tool("fuzz_parity")
+    print(fz.one_case(pp, util_ref, seed))
+
+
+@pytest.mark.parametrize("seed", [20000, 20001, 20002, 20003, 5212, 5120])
+def test_fuzz_train_seeds(pp, hip_lib, seed):
+    """A few cases of the randomised training-step soak (round 4: 442 cases in both forward modes, none unexplained):
+    losses, every gradient against torch autograd, a bit-identical second pass.  Seeds 5212 and 5120 are the
+    documented hard kind: a pre-ReLU value of 1e-7 (float64) in one layer -- the soak must classify them as
+    near-kink cases whose differences stay inside the cone of layers in front of that element, not wave them through."""
+    from oracle import train_ref
+    ft = _tool("fuzz_train")
+    res = ft.one_case(pp, util_ref, train_ref, _tool("fuzz_parity"), seed)
+    print(res)
+    assert res.startswith("AMBIGUOUS") == (seed in (5212, 5120)), res
