@@ -27,10 +27,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 TOL = 1e-4
 
 
+LARGE = False       # --large: KITTI-sized, mostly empty grids (the sparse first layer, the pillar-centric PFN, frame sub-ranges)
+
+
 def random_config(pp, rng, B):
     cfg = copy.deepcopy(pp.config.pedestrian_d435i_config(B))
     s1 = int(rng.choice([1, 2]))
     nx, ny = 4 * s1 * int(rng.integers(3, 14)), 4 * s1 * int(rng.integers(2, 12))
+    if LARGE:
+        nx, ny = 8 * int(rng.integers(20, 63)), 8 * int(rng.integers(20, 63))
     v = float(rng.choice([0.08, 0.16]))
     nz2 = bool(rng.integers(0, 2))
     zr = (-3.0, 3.0) if nz2 else (-3.0, 1.0)
@@ -69,6 +74,8 @@ def random_frames(rng, d, B):
     for b in range(B):
         kind = int(rng.integers(0, 8))
         n = 0 if kind == 0 else int(rng.integers(1, 60)) if kind == 1 else int(rng.integers(300, 6000))
+        if LARGE and kind > 1:
+            n = int(rng.integers(2000, 20000))
         xyz = rng.uniform(lo - 0.2, hi + 0.2, (n, 3))
         if kind == 2 and n:                      # a crowd in a few pillars
             c = rng.uniform(lo, hi, (4, 3))
@@ -80,9 +87,9 @@ def random_frames(rng, d, B):
 
 def one_case(pp, util_ref, seed):
     rng = np.random.default_rng(seed)
-    B = int(rng.choice([1, 2, 3, 5, 8, 17, 32]))
+    B = int(rng.choice([1, 2, 3, 5, 8, 17, 32])) if not LARGE else int(rng.choice([1, 2, 4, 9]))
     cfg = random_config(pp, rng, B)
-    eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=8192)
+    eng = pp.Engine(cfg, max_batch=B, max_points_per_frame=8192 if not LARGE else 20480)
     try:
         d = eng.d
         w = pp.weights.init_weights(d, seed=seed)
@@ -154,7 +161,10 @@ def main():
     ap.add_argument("--max-cases", type=int, default=100000)
     ap.add_argument("--out", default=None)
     ap.add_argument("--seeds", default=None, help="comma-separated seeds to run instead of the timed sweep")
+    ap.add_argument("--large", action="store_true", help="KITTI-sized grids (160..496 cells a side), up to 20 000 points, batches 1..9")
     a = ap.parse_args()
+    global LARGE
+    LARGE = a.large
     import pp_amd as pp
     import util_ref
     pp._lib.build()
