@@ -818,7 +818,7 @@ def test_fuzz_parity_seeds(pp, hip_lib, seed):
     bars): random grids / strides / widths / classes / NMS settings / batch sizes 1..32.  Seeds 1081 and 1304 hold two
     boxes whose scores agree to 1e-7 (the reference's order of equal scores is implementation-defined: the soak
     accepts a swap among equal scores and nothing else), 10758 a 32 m box (sizes are exp(t) * anchor: compared to 1e-4
-    + 1e-5 of their size)."""
+    + 1e-4 of their size)."""
     fz = _tool("fuzz_parity")
     print(fz.one_case(pp, util_ref, seed))
 

@@ -7,7 +7,7 @@ counts, class count, direction head, distance feature, pillar caps, NMS sizes an
 both sides of the engine's kernel selection (a handful of frames: the split-K small-map kernels; dozens: the
 persistent ones), random clouds (empty frames, points outside the range, crowded pillars).  The HIP path through the
 C-ABI is compared with the oracle exactly as tests/test_gpu_parity.py::test_random_small_configs_end_to_end does
-(pillars / anchor mask bit-exact, head maps within 1e-4, boxes within 1e-4 + 1e-5 of their size; rows that
+(pillars / anchor mask bit-exact, head maps within 1e-4, boxes within 1e-4 + 1e-4 of their size; rows that
 changed places must share their score: the reference's order of equal scores is implementation-defined).  TEST INFRASTRUCTURE: imports oracle/.
 Prints one line per case and a summary; exit code 1 on any mismatch (the failing seed reproduces the case).
 """
@@ -126,9 +126,10 @@ def one_case(pp, util_ref, seed):
             ndet += k
             rows_a = np.concatenate([a["box3d_lidar"], a["box3d_camera"], a["scores"][:, None], a["label_preds"][:, None]], axis=1)
             rows_r = np.concatenate([r["box3d_lidar"], r["box3d_camera"], r["scores"][:, None], r["label_preds"][:, None]], axis=1)
-            # decoded sizes are exp(t) * anchor: with random weights a box can be 50 m long and carry the head map's 1e-6
-            # relative error as 1e-4 absolute -- rows are compared to 1e-4 + 1e-5 * |oracle| (in units of that bound)
-            scale = lambda ref_rows: TOL + 1e-5 * np.abs(ref_rows)      # noqa: E731
+            # decoded sizes are exp(t) * anchor: an error e of the head value t (bar: 1e-4) is a RELATIVE error e of the size,
+            # and random weights produce t = 17 (a 2e7 m box, whose t carries 1e-5 of float32 round-off) -- rows are
+            # compared to 1e-4 + 1e-4 * |oracle| (in units of that bound)
+            scale = lambda ref_rows: TOL + 1e-4 * np.abs(ref_rows)      # noqa: E731
             if np.max(np.abs(rows_a - rows_r) / scale(rows_r)) <= 1.0:
                 continue
             # Not the same rows in the same order.  The one accepted reason (deviation 2): the order of
