@@ -33,7 +33,7 @@ EXPORTS = [
     "pp_timer_start", "pp_timer_stop", "pp_device_info", "pp_device_copy_bench", "pp_device_mem_free", "pp_bench_layer", "pp_layer_count", "pp_layer_tag",
     "pp_rotate_iou_eval", "pp_d3_box_overlap", "pp_head_loss", "pp_adamw_step_device",
     "pp_train_layout", "pp_train_layout_entry", "pp_train_step", "pp_train_step_async", "pp_train_step_wait",
-    "pp_train_graph_stats", "pp_stream",
+    "pp_train_graph_stats", "pp_stream", "pp_train_fetch_decisions",
 ]
 
 
@@ -245,6 +245,7 @@ def lib():
     L.pp_train_step_wait.argtypes = [vp, f32p]
     L.pp_stream.argtypes = [vp, ctypes.POINTER(vp)]
     L.pp_train_graph_stats.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.pp_train_fetch_decisions.argtypes = [vp, i32, vp, i64, ctypes.POINTER(i64)]
     L.pp_adamw_step_device.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, i64, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_float]
     for name in EXPORTS:

@@ -153,6 +153,7 @@ struct pp_engine {
             const void *params = nullptr, *grads = nullptr, *state = nullptr;
             pp_loss_config loss;
         } graph[2];
+        int last_batch = 0;    // frames of the last step (pp_train_fetch_decisions)
         int graph_state = 0;   // -1: capture failed once, plain launches from then on
         int n_captures = 0, n_replays = 0;   // pp_train_graph_stats
     };
@@ -2144,6 +2145,7 @@ int pp_train_step_async(pp_handle e, const float* params_dev, float* grads_dev, 
     e->results_batch = 0;          // the head map now holds training-mode outputs, not detections
     e->cls_plane_live = false;
     e->train_pending = true;
+    t->last_batch = batch;
     return PP_OK;
 }
 
@@ -2172,6 +2174,46 @@ int pp_stream(pp_handle e, void** stream) {
     if (!stream) return fail(e, PP_ERR_ARG, "pp_stream: stream is NULL");
     *stream = (void*)e->stream;
     return PP_OK;
+}
+
+int pp_train_fetch_decisions(pp_handle e, int32_t layer, uint8_t* relu_mask, int64_t capacity, int64_t* count) {
+    if (!e) return PP_ERR_ARG;
+    if (!count) return fail(e, PP_ERR_ARG, "pp_train_fetch_decisions: count is NULL");
+    if (!e->train || !e->train->buffers || e->train->last_batch < 1)
+        return fail(e, PP_ERR_STATE, "pp_train_fetch_decisions: no training step to tap");
+    if (e->train_pending) return fail(e, PP_ERR_STATE, "pp_train_fetch_decisions: the step has not been waited for");
+    (void)hipSetDevice(e->device);
+    pp_engine::TrainState* t = e->train;
+    const size_t B = (size_t)t->last_batch;
+    if (layer < 0) {      // the PFN: winning row per (pillar slot, channel), int32 stored as 4 bytes each
+        const int64_t n = (int64_t)B * t->shape.max_voxels * t->shape.C;
+        *count = n;
+        if (!relu_mask) return PP_OK;
+        if (capacity < n * 4) return fail(e, PP_ERR_ARG, "pp_train_fetch_decisions: %lld bytes needed", (long long)(n * 4));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        HIPCHK(e, hipMemcpy(relu_mask, t->cx.pfn_arg, (size_t)n * 4, hipMemcpyDeviceToHost));
+        return PP_OK;
+    }
+    int k = -1;
+    for (size_t i = 0; i < t->shape.layers.size(); ++i) {
+        const LayerDesc& l = t->shape.layers[i];
+        if (l.kind != LAYER_SEP && l.kind != LAYER_DECONV) continue;
+        if (++k != layer) continue;
+        const int64_t n = (l.kind == LAYER_SEP) ? (int64_t)B * l.out_h * l.out_w * l.cout
+                                                : (int64_t)B * l.in_h * l.in_w * l.k * l.k * l.cout;
+        *count = n;
+        if (!relu_mask) return PP_OK;
+        if (capacity < n) return fail(e, PP_ERR_ARG, "pp_train_fetch_decisions: %lld bytes needed", (long long)n);
+        unsigned char* d = nullptr;
+        HIPCHK(e, hipMalloc(&d, (size_t)n));
+        launch_relu_mask(t->cx.lbuf[i].Z, t->cx.lbuf[i].coef, (long)n, l.cout, d, e->stream);
+        hipError_t he = hipStreamSynchronize(e->stream);
+        if (he == hipSuccess) he = hipMemcpy(relu_mask, d, (size_t)n, hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        if (he != hipSuccess) return fail(e, PP_ERR_HIP, "pp_train_fetch_decisions: %s", hipGetErrorString(he));
+        return PP_OK;
+    }
+    return fail(e, PP_ERR_ARG, "pp_train_fetch_decisions: layer %d out of range", layer);
 }
 
 int pp_train_graph_stats(pp_handle e, int32_t* captures, int32_t* replays) {

@@ -80,3 +80,7 @@ size_t train_part_floats(const TrainShape& s);
 // forward (training mode) + loss + backward for `batch` resident, voxelised frames; grads overwritten, state updated
 int train_step(const TrainCtx& cx, const TrainShape& s, const std::vector<TrainEntry>& layout, const float* params,
                float* grads, float* state, int batch, const LossParams& loss, int phase = 3);
+
+// parity tap (pp_train_fetch_decisions): mask[i] = 1 where the backward pass lets the gradient through element i of
+// Z[n] ([rows][C]; the test the BatchNorm-backward kernels make: fmaf(z, sc, sh) > 0)
+void launch_relu_mask(const float* Z, const float4* coef, long n, int C, unsigned char* mask, hipStream_t s);

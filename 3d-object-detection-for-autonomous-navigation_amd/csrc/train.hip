@@ -1161,6 +1161,19 @@ __global__ __launch_bounds__(256) void k_tr_bn_finalize(const float* __restrict_
     }
 }
 
+// parity tap: the ReLU decisions of a layer as the backward kernels take them (k_tr_bn_bwd_reduce / _apply, k_tr_dw_bwd)
+__global__ __launch_bounds__(256) void k_tr_relu_mask(const float* __restrict__ Z, const float4* __restrict__ coef, long n, int C,
+                                                      unsigned char* __restrict__ mask) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = coef[(int)(i % C)];
+    mask[i] = (fmaf(Z[i], q.x, q.y) > 0.f) ? 1 : 0;
+}
+void launch_relu_mask(const float* Z, const float4* coef, long n, int C, unsigned char* mask, hipStream_t s) {
+    if (n <= 0) return;
+    k_tr_relu_mask<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(Z, coef, n, C, mask);
+}
+
 // row of the [rows][C] matrix -> pixel row of the destination activation (identity, or the pixel shuffle of a
 // transposed convolution with kernel == stride k: row = input pixel * k*k + tap)
 struct RowMap { int k, in_h, in_w; };

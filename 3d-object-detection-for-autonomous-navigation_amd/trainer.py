@@ -99,6 +99,40 @@ class Trainer:
         g = self.grads.cpu().numpy()
         return {name: g[off:off + size].reshape(shapes[name]).copy() for name, off, size, st in self.layout if not st}
 
+    def decisions(self):
+        """Parity tap (pp_train_fetch_decisions): what the last step decided at its non-differentiable points.
+        {"pfn": int32 [batch, max_voxels, C] winning row of every pillar slot (-1 a padded row, -2 no gradient),
+         "<layer>/bn": bool mask of the layer's ReLU in NCHW order (as a torch graph of the network holds the tensor)}
+        for every separable layer and transposed convolution, forward order."""
+        import ctypes
+        from . import weights as _w
+        eng = self.engine
+        d = eng.d
+        L = eng._lib
+
+        def fetch(layer, itemsize):
+            n = ctypes.c_int64(0)
+            eng._check(L.pp_train_fetch_decisions(eng._h, layer, None, 0, ctypes.byref(n)), "pp_train_fetch_decisions")
+            buf = np.empty(n.value * itemsize, np.uint8)
+            eng._check(L.pp_train_fetch_decisions(eng._h, layer, buf.ctypes.data_as(ctypes.c_void_p), buf.size,
+                                                  ctypes.byref(n)), "pp_train_fetch_decisions")
+            return buf
+        out = {}
+        arg = fetch(-1, 4).view(np.int32)
+        out["pfn"] = arg.reshape(-1, d.max_voxels, d.pfn_filters)
+        B = out["pfn"].shape[0]
+        k = 0
+        for kind, name, s in _w.layer_table(d):
+            if kind == "head":
+                continue
+            m = fetch(k, 1).astype(bool)
+            k += 1
+            if kind == "sep":
+                out[name + "/bn"] = m.reshape(B, -1, s["cout"])             # [b][pixels][c]; the caller knows H x W
+            else:
+                out[name + "/bn"] = m.reshape(B, -1, s["k"], s["k"], s["cout"])   # [b][input pixels][ti][tj][c]
+        return out
+
     # ---- one optimizer step ----
     def stage(self, frames, labels, reg_targets):
         """A training batch in page-locked host memory: the points as an engine Staging, labels / regression targets

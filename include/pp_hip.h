@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 3
+#define PP_ABI_VERSION 4
 
 enum pp_status {
     PP_OK = 0,
@@ -343,6 +343,17 @@ int pp_train_step_wait(pp_handle h, float* losses);
  * -- the gradient all-reduce and pp_adamw_step_device of the optimizer step (train.py:301) -- does it on this stream and
  * needs no host synchronisation in between: pp_train_step_wait then waits for that work too. */
 int pp_stream(pp_handle h, void** stream);
+
+/* Debug / parity tap of the last finished training step: the decisions taken at its non-differentiable points.
+ * layer >= 0: the layer-th BatchNorm + ReLU of the RPN in forward order (separable layers and transposed convolutions
+ * as the network lists them: block1/0 .., deconv1, block2/0 .., deconv2, ...): relu_mask receives one byte per element
+ * of the layer's pre-BatchNorm output ([b][y][x][c]; a transposed convolution: [b][y][x][tap][c] over its INPUT
+ * pixels), 1 where the backward pass lets the gradient through.  layer < 0: the PFN's max -- relu_mask receives
+ * int32 values (4 bytes each) [batch][max_voxels][C]: the winning row of the pillar, -1 = a zero-padded row, -2 = the
+ * maximum is not positive (no gradient); slots >= the frame's pillar count are undefined.  *count = elements of that
+ * layer; relu_mask NULL: only the count.  A test compares the step's gradients with a float64 graph that takes the
+ * SAME decisions (ReLU and max are not differentiable where a value is within round-off of the kink). */
+int pp_train_fetch_decisions(pp_handle h, int32_t layer, uint8_t* relu_mask, int64_t capacity, int64_t* count);
 
 /* How often pp_train_step captured a hipGraph and how often it replayed one (one graph per input buffer of the
  * handle): steady-state steps must replay -- a regression check, not part of the reference's surface. */

@@ -30,7 +30,8 @@ def _bn_train(x, gamma, beta, dims):
     return (x - mean) / torch.sqrt(var + BN_EPS) * gamma.reshape(shape) + beta.reshape(shape), mean.flatten(), var.flatten()
 
 
-def training_step(d, w, example, labels, reg_targets, anchors, num_threads=None, dtype=torch.float32, margins=None):
+def training_step(d, w, example, labels, reg_targets, anchors, num_threads=None, dtype=torch.float32, margins=None,
+                  forced=None, record=None):
     """d: config.Derived; w: Keras-layout dict of numpy arrays; example: the oracle's merged batch (padded voxels,
     num_points, coors[b,z,y,x], ...).  Returns (loss dict of floats, gradient dict name -> numpy for every trainable
     tensor, batch statistics dict name -> (mean, biased var)).  dtype=torch.float64: the same graph in double
@@ -38,7 +39,12 @@ def training_step(d, w, example, labels, reg_targets, anchors, num_threads=None,
     margins: a dict that receives, per BatchNorm + ReLU layer, the smallest |pre-ReLU value| of the step (and for the PFN
     the smallest positive gap between a pillar's largest and second-largest row): ReLU and max are not differentiable
     there, so an implementation whose round-off puts such an element on the other side returns a gradient that differs
-    by that element's whole contribution -- a property of the problem, not an error (tools/fuzz_train.py uses it)."""
+    by that element's whole contribution -- a property of the problem, not an error (tools/fuzz_train.py uses it).
+    forced: the decisions another implementation took at those points (Trainer.decisions(): {"pfn": winning row per
+    (pillar, channel) in this example's pillar order, -1 a padded row, -2 none; "<layer>/bn": ReLU mask [B, pixels, C],
+    transposed convolutions [B, input pixels, k, k, C]}): the graph then takes the SAME branches (relu(x) -> x * mask, max ->
+    the given row), which makes its gradient a smooth function of the inputs and the comparison sharp.
+    record: a dict that receives this run's own decisions in that format (self-check of the forced path)."""
     if num_threads:
         torch.set_num_threads(num_threads)
     voxels, num_points, coors = example[0], example[1], example[2]
@@ -51,7 +57,18 @@ def training_step(d, w, example, labels, reg_targets, anchors, num_threads=None,
     y = feats @ t["pfn/dense/kernel"]                                  # [P, T, C]
     yn, m, v = _bn_train(y, t["pfn/bn/gamma"], t["pfn/bn/beta"], (0, 1))
     stats["pfn/bn"] = (m.detach().numpy(), v.detach().numpy())
-    f = torch.relu(yn).amax(dim=1)                                      # [P, C]
+    if record is not None:
+        with torch.no_grad():
+            best, bi = yn.max(dim=1)
+            bi = torch.where(bi >= torch.from_numpy(num_points.astype(np.int64))[:, None], torch.full_like(bi, -1), bi)
+            record["pfn"] = torch.where(best > 0, bi, torch.full_like(bi, -2)).numpy().astype(np.int32)
+    if forced is not None:
+        arg = torch.from_numpy(np.ascontiguousarray(forced["pfn"]).astype(np.int64))          # [P, C]
+        pad_row = torch.from_numpy(np.minimum(num_points.astype(np.int64), yn.shape[1] - 1))[:, None].expand_as(arg)
+        idx = torch.where(arg >= 0, arg, pad_row)
+        f = yn.gather(1, idx[:, None, :]).squeeze(1) * (arg != -2).to(dtype)
+    else:
+        f = torch.relu(yn).amax(dim=1)                                  # [P, C]
     if margins is not None:
         with torch.no_grad():
             top = torch.topk(torch.relu(yn), 2, dim=1).values if yn.shape[1] > 1 else None
@@ -75,15 +92,33 @@ def training_step(d, w, example, labels, reg_targets, anchors, num_threads=None,
             stats[pre + "/bn"] = (m.detach().numpy(), v.detach().numpy())
             if margins is not None:
                 margins[pre + "/bn"] = float(x.detach().abs().min())
-            x = torch.relu(x)
+                margins["#near-kink"] = margins.get("#near-kink", 0) + int((x.detach().abs() < 1e-6).sum())
+                margins["#pre-relu"] = margins.get("#pre-relu", 0) + x.numel()
+            if record is not None:
+                record[pre + "/bn"] = (x.detach() > 0).permute(0, 2, 3, 1).reshape(x.shape[0], -1, x.shape[1]).numpy()
+            if forced is not None:
+                m = torch.from_numpy(np.ascontiguousarray(forced[pre + "/bn"])).reshape(x.shape[0], x.shape[2], x.shape[3], x.shape[1])
+                x = x * m.permute(0, 3, 1, 2).to(dtype)
+            else:
+                x = torch.relu(x)
         pre = f"rpn/deconv{b + 1}"
         k = d.upsample_strides[b]
+        in_h, in_w = x.shape[2], x.shape[3]
         u = Fn.conv_transpose2d(x, t[pre + "/kernel"].permute(3, 2, 0, 1), stride=k)   # [k,k,Cout,Cin] -> [Cin,Cout,k,k]
         u, m, v = _bn_train(u, t[pre + "/bn/gamma"], t[pre + "/bn/beta"], (0, 2, 3))
         stats[pre + "/bn"] = (m.detach().numpy(), v.detach().numpy())
         if margins is not None:
             margins[pre + "/bn"] = float(u.detach().abs().min())
-        ups.append(torch.relu(u))
+            margins["#near-kink"] = margins.get("#near-kink", 0) + int((u.detach().abs() < 1e-6).sum())
+            margins["#pre-relu"] = margins.get("#pre-relu", 0) + u.numel()
+        if record is not None:
+            record[pre + "/bn"] = (u.detach() > 0).reshape(u.shape[0], u.shape[1], in_h, k, in_w, k).permute(0, 2, 4, 3, 5, 1) \
+                .reshape(u.shape[0], in_h * in_w, k, k, u.shape[1]).numpy()
+        if forced is not None:       # [B, input pixels, ti, tj, C] -> [B, C, in_h * k + ti, in_w * k + tj]
+            m = torch.from_numpy(np.ascontiguousarray(forced[pre + "/bn"])).reshape(u.shape[0], in_h, in_w, k, k, u.shape[1])
+            ups.append(u * m.permute(0, 5, 1, 3, 2, 4).reshape(u.shape).to(dtype))
+        else:
+            ups.append(torch.relu(u))
     cat = torch.cat(ups, dim=1)
 
     def head(name):

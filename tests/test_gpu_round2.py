@@ -828,7 +828,8 @@ def test_fuzz_train_seeds(pp, hip_lib, seed):
     """A few cases of the randomised training-step soak (round 4: 442 cases in both forward modes, none unexplained):
     losses, every gradient against torch autograd, a bit-identical second pass.  Seeds 5212 and 5120 are the
     documented hard kind: a pre-ReLU value of 1e-7 (float64) in one layer -- the soak must classify them as
-    near-kink cases whose differences stay inside the cone of layers in front of that element, not wave them through."""
+    near-kink cases AND find the gradients within 1e-4 of the float64 graph that takes the step's own ReLU / max
+    decisions (pp_train_fetch_decisions), not wave them through."""
     from oracle import train_ref
     ft = _tool("fuzz_train")
     res = ft.one_case(pp, util_ref, train_ref, _tool("fuzz_parity"), seed)

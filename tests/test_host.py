@@ -106,7 +106,7 @@ def test_cabi_exports_every_declared_symbol(pp, hip_lib):
     assert declared == set(pp._lib.EXPORTS), declared ^ set(pp._lib.EXPORTS)
     for name in declared:
         assert hasattr(hip_lib, name), name
-    assert hip_lib.pp_abi_version() == 3
+    assert hip_lib.pp_abi_version() == 4
 
 
 def test_struct_layouts_match_header(pp):

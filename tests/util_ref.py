@@ -37,3 +37,15 @@ def oracle_detect(d, w, frames, rect, trv2c, p2, num_threads=None):
     preds, canvas, feats = oracle_forward(d, w, ex, num_threads)
     dets = rn.predict(ex, preds, d.nms_dict())
     return {"example": ex, "frames": fr, "preds": preds, "canvas": canvas, "features": feats, "dets": dets}
+
+
+def forced_decisions(trainer, example):
+    """Trainer.decisions() (the GPU step's ReLU masks and PFN winners) in the form oracle/train_ref.py takes as `forced`:
+    the PFN rows of the frames' real pillars, in the oracle example's pillar order (frame-major)."""
+    dec = trainer.decisions()
+    coors = example[2]
+    B = dec["pfn"].shape[0]
+    counts = [int((coors[:, 0] == b).sum()) for b in range(B)]
+    out = {k: v for k, v in dec.items() if k != "pfn"}
+    out["pfn"] = np.concatenate([dec["pfn"][b, :counts[b]] for b in range(B)], axis=0)
+    return out
