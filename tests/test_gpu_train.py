@@ -360,3 +360,42 @@ def test_fused_forward_kernels_on_small_grids(hip_lib):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "6 passed" in r.stdout, r.stdout[-1000:]
+
+
+def test_decisions_tap_surface(pp, hip_lib):
+    """pp_train_fetch_decisions: state and argument errors, shapes, and that the masks are the ones the step used --
+    an element the mask lets through has a positive activation in the oracle's float64 run unless it lies within
+    round-off of zero."""
+    import ctypes
+    import torch
+    B = 2
+    cfg = pp.config.tiny_config(B)
+    d = pp.config.Derived(cfg)
+    rng = np.random.default_rng(6)
+    frames = [rng.uniform([0, -0.64, -3], [1.6, 0.64, 3], (n, 3)).astype(np.float32) for n in (700, 300)]
+    d, labels, reg = _problem(pp, cfg, frames, 5, npos=12)
+    w = pp.weights.init_weights(d, seed=9)
+    tr = pp.Trainer(cfg, w, max_batch=B, max_points_per_frame=4096)
+    eng = tr.engine
+    n = ctypes.c_int64(0)
+    assert eng._lib.pp_train_fetch_decisions(eng._h, 0, None, 0, ctypes.byref(n)) == 3      # PP_ERR_STATE: no step yet
+    tr.forward_backward(frames, labels, reg)
+    assert eng._lib.pp_train_fetch_decisions(eng._h, 0, None, 0, None) == 1                  # PP_ERR_ARG: count is NULL
+    assert eng._lib.pp_train_fetch_decisions(eng._h, 99, None, 0, ctypes.byref(n)) == 1      # no such layer
+    assert eng._lib.pp_train_fetch_decisions(eng._h, 0, None, 0, ctypes.byref(n)) == 0 and n.value == B * 16 * 20 * 32
+    small = np.zeros(8, np.uint8)
+    assert eng._lib.pp_train_fetch_decisions(eng._h, 0, small.ctypes.data_as(ctypes.c_void_p), 8, ctypes.byref(n)) == 1
+    dec = tr.decisions()
+    assert dec["pfn"].shape == (B, d.max_voxels, d.pfn_filters) and dec["pfn"].dtype == np.int32
+    assert dec["rpn/block1/0/bn"].shape == (B, 16 * 20, 32) and dec["rpn/deconv3/bn"].shape == (B, 4 * 5, 4, 4, 32)
+    rect, trv, p2 = pp.synth.default_calib()
+    ex, _ = util_ref.oracle_example(d, frames, rect, trv, p2)
+    rec, marg = {}, {}
+    train_ref.training_step(d, w, ex, labels, reg, ex[6][0], dtype=torch.float64, record=rec, margins=marg)
+    forced = util_ref.forced_decisions(tr, ex)
+    differ = {k: int((np.asarray(forced[k]) != np.asarray(rec[k]).reshape(np.asarray(forced[k]).shape)).sum()) for k in rec}
+    total = sum(np.asarray(v).size for v in rec.values())
+    print(f"decisions that differ from the float64 run: {sum(differ.values())} of {total} "
+          f"({ {k: v for k, v in differ.items() if v} }); smallest margin {min(v for k, v in marg.items() if not k.startswith('#')):.1e}")
+    assert sum(differ.values()) <= 5          # (a handful of elements within round-off of a kink, typically none)
+    tr.close()
