@@ -234,7 +234,7 @@ def corner_to_standup(corners):
 
 
 # --------------------------------------------------------------------------
-# a10/a11  NMS                    host sweep PINNED; kernel restated (numba-CUDA)
+# a10/a11  NMS      nms(), nms_gpu, nms_kernel, host sweep PINNED (ref_cuda_kernels.npz: the reference kernels on an emulator)
 # --------------------------------------------------------------------------
 def nms_iou(a, b):
     """libraries/eval_helper_functions.py:553-564 (iou_device).  Inputs f32; the

@@ -59,6 +59,16 @@ def test_oracle_rotate_iou_matches_reference():
     assert (g["iou_c-1"] > 0).sum() > 200 and g["iou_c-1"].max() <= 1.0
 
 
+def test_oracle_rotate_iou_matches_the_reference_kernel():
+    """ref_cuda_kernels.npz: rotate_iou_gpu_eval -> rotate_iou_kernel_eval itself (nms_gpu.py:493-527, :618-653), run by the
+    CUDA-model emulator of tools/ref_shim.py on 70 x 130 boxes (block edges in both grid dimensions)."""
+    g = load_golden("ref_cuda_kernels.npz")
+    for crit in (-1, 1):
+        out = c_oracle.rotate_iou_eval(g["riou_boxes"], g["riou_qboxes"], crit)
+        assert np.array_equal(out, g[f"riou_c{crit}"]), crit
+    assert (g["riou_c-1"] > 0).sum() > 1000
+
+
 def test_oracle_overlaps_match_reference_per_frame(pp):
     g = load_golden("ref_kitti_eval.npz")
     gts, dts = _annos(g)
@@ -122,6 +132,14 @@ def test_hip_rotate_iou_matches_reference(pp, hip_lib):
         out = pp.kitti_eval.rotate_iou_eval(g["boxes"], g["qboxes"], crit)
         assert out.dtype == np.float32 and out.shape == g[f"iou_c{crit}"].shape
         assert np.array_equal(out, g[f"iou_c{crit}"]), (crit, np.abs(out - g[f"iou_c{crit}"]).max())
+
+
+@pytest.mark.gpu
+def test_hip_rotate_iou_matches_the_reference_kernel(pp, hip_lib):
+    g = load_golden("ref_cuda_kernels.npz")
+    for crit in (-1, 1):
+        out = pp.kitti_eval.rotate_iou_eval(g["riou_boxes"], g["riou_qboxes"], crit)
+        assert np.array_equal(out, g[f"riou_c{crit}"]), (crit, np.abs(out - g[f"riou_c{crit}"]).max())
 
 
 @pytest.mark.gpu

@@ -108,9 +108,42 @@ def test_lidar_to_camera_matches_reference():
         assert cam.dtype == np.float64 and np.array_equal(cam, g["cam" + s])
 
 
+def test_nms_gpu_matches_the_reference_kernel():
+    """ref_cuda_kernels.npz: the reference's nms_gpu -> nms_kernel -> nms_postprocess (libraries/eval_helper_functions.py:
+    494-598) run as they are by the CUDA-model emulator of tools/ref_shim.py (round 4: the kernel's block / thread
+    indexing, shared staging and bit masks are no longer unpinned): box counts on both sides of the 64-thread blocks,
+    three thresholds, no pair within 1e-4 of a threshold."""
+    g = load_golden("ref_cuda_kernels.npz")
+    ncases = 0
+    for thr in (0.5, 0.1, 0.7):
+        for n in (1, 2, 63, 64, 65, 100, 129, 200):
+            dets, keep = g[f"nms_t{thr}_n{n}_dets"], g[f"nms_t{thr}_n{n}_keep"]
+            assert list(rn.nms_gpu(dets, thr)) == list(keep), (thr, n)
+            order = np.argsort(-dets[:, 4], kind="stable")              # (scores are a permutation: no ties)
+            k_c = c_oracle.nms_sorted(np.ascontiguousarray(dets[order]), thr)
+            assert [int(order[i]) for i in k_c] == list(keep), (thr, n)
+            ncases += 1
+    assert ncases == 24 and len(g["nms_t0.1_n200_keep"]) < 40 < len(g["nms_t0.7_n200_keep"])
+
+
+def test_nms_function_matches_the_reference():
+    """nms() as the reference wrote it (libraries/eval_helper_functions.py:463-492: np.argpartition top pre_max_size,
+    nms_gpu on the emulated kernel, post_max_size, None for nothing kept): the numpy-1.19 list-index idiom it uses runs
+    through an ndarray subclass with the old meaning (tools/gen_golden_kernels.py)."""
+    g = load_golden("ref_cuda_kernels.npz")
+    for k in range(int(g["nmsfn_count"])):
+        pre, post, thr = g[f"nmsfn_{k}_args"]
+        got = rn.nms(g[f"nmsfn_{k}_boxes"], g[f"nmsfn_{k}_scores"], None if pre < 0 else int(pre), int(post), float(thr))
+        if bool(g[f"nmsfn_{k}_none"]):
+            assert got is None
+        else:
+            assert np.array_equal(np.asarray(got, dtype=np.int64), g[f"nmsfn_{k}_keep"]), k
+    assert int(g["nmsfn_count"]) == 6
+
+
 def test_nms_kernel_restatements_agree():
-    """numba-CUDA nms_kernel is unpinned (cannot run here): the numpy and C
-    restatements are written independently and must agree with each other."""
+    """The numpy and C restatements of nms_kernel are written independently and must agree with each other (beside the
+    fixture above)."""
     rng = np.random.default_rng(5)
     for n in (1, 5, 64, 100, 131):
         c = rng.uniform(0, 6, (n, 2)).astype(np.float32)

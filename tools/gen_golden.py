@@ -15,8 +15,8 @@ executed (paths relative to /root/reference):
     eval_helper_functions.second_box_decode       libraries/eval_helper_functions.py:388-461
     eval_helper_functions.nms_postprocess         libraries/eval_helper_functions.py:529-546
     eval_helper_functions.box_lidar_to_camera     libraries/eval_helper_functions.py:735-740
-Not runnable here (TensorFlow / numba.cuda / numpy>=1.23 list-index idiom):
-PillarFeatureNet, PointPillarsScatter, RPN, nms(), nms_gpu, nms_kernel, predict().
+Not runnable here (TensorFlow): PillarFeatureNet, PointPillarsScatter, RPN, predict().
+nms(), nms_gpu and nms_kernel run through the CUDA-model emulator of ref_shim.py: tools/gen_golden_kernels.py.
 """
 import hashlib
 import os

@@ -13,6 +13,16 @@ friends become identity decorators so the decorated functions run as plain
 Python, and `np.meshgrid` is wrapped to return a list (numpy>=2 returns a
 tuple, the reference mutates the result, load_data.py:1630-1633).
 Recipe recorded in SURVEY.md section 8c.
+
+Round 4: `numba.cuda` is no longer an empty stand-in but a small EMULATOR of the CUDA execution model (below:
+_CudaEmu), so that the reference's kernels themselves -- `nms_kernel` (libraries/eval_helper_functions.py:567-598) and
+`rotate_iou_kernel_eval` (second/core/non_max_suppression/nms_gpu.py:493-527), with their block / thread indexing,
+shared-memory staging and `syncthreads` -- run unmodified through the reference's own host wrappers (`nms_gpu`,
+`rotate_iou_gpu_eval`): one Python thread per CUDA thread of a block, a barrier for `syncthreads`, one array per
+`cuda.shared.array` call site and block.  (The image's second interpreter has a real numba, but it does not import
+against that interpreter's numpy: an ordinary SystemError.)  Arithmetic caveat, as for the device functions before:
+plain Python keeps float32 + integer literal in float32 where numba types it float64, so fixtures made this way pin
+indexing and decisions (inputs are drawn with margins), not the last bit of an IoU.
 """
 import importlib
 import importlib.abc
@@ -64,6 +74,12 @@ class _Anything(types.ModuleType):
         if name.startswith("__") and name.endswith("__"):
             raise AttributeError(name)
         full = self.__name__ + "." + name
+        if full == "numba.cuda":
+            mod = sys.modules.get(full)
+            if not isinstance(mod, _CudaEmu):
+                mod = _CudaEmu()
+                sys.modules[full] = mod
+            return mod
         if name in ("jit", "njit", "autojit", "vectorize", "guvectorize"):
             return _identity_decorator
         if self.__name__.split(".")[0] == "numba":
@@ -91,6 +107,129 @@ class _Anything(types.ModuleType):
         return iter(())
 
 
+class _Dim3:
+    def __init__(self, x=0, y=0, z=0):
+        self.x, self.y, self.z = x, y, z
+
+
+class _DevArray:
+    """cuda.to_device result: the kernels index it like an array; copy_to_host writes back."""
+
+    def __init__(self, a):
+        self.a = np.array(a, copy=True)
+
+    def copy_to_host(self, ary=None, stream=None):
+        if ary is None:
+            return self.a.copy()
+        ary[...] = self.a.reshape(ary.shape)
+        return ary
+
+
+class _Stream:
+    def auto_synchronize(self):
+        import contextlib
+        return contextlib.nullcontext(self)
+
+    def synchronize(self):
+        pass
+
+
+class _CudaKernel:
+    def __init__(self, emu, fn):
+        self.emu, self.fn = emu, fn
+
+    def __getitem__(self, cfg):
+        grid, block = cfg[0], cfg[1]
+        grid = tuple(grid) if isinstance(grid, (tuple, list)) else (int(grid),)
+        block = tuple(block) if isinstance(block, (tuple, list)) else (int(block),)
+        grid = tuple(int(g) for g in grid) + (1,) * (3 - len(grid))
+        block = tuple(int(b) for b in block) + (1,) * (3 - len(block))
+
+        def launch(*args):
+            import threading
+            args = [a.a if isinstance(a, _DevArray) else a for a in args]
+            nthreads = block[0] * block[1] * block[2]
+            for bz in range(grid[2]):
+                for by in range(grid[1]):
+                    for bx in range(grid[0]):
+                        state = {"barrier": threading.Barrier(nthreads), "shared": {}, "lock": threading.Lock()}
+                        errors = []
+
+                        def run(tx, ty, tz):
+                            tls = self.emu._tls
+                            tls.threadIdx, tls.blockIdx = _Dim3(tx, ty, tz), _Dim3(bx, by, bz)
+                            tls.blockDim, tls.gridDim = _Dim3(*block), _Dim3(*grid)
+                            tls.state, tls.nshared = state, 0
+                            try:
+                                self.fn(*args)
+                            except BaseException as ex:  # noqa: BLE001
+                                errors.append(ex)
+                                state["barrier"].abort()
+                        ts = [threading.Thread(target=run, args=(tx, ty, tz)) for tz in range(block[2])
+                              for ty in range(block[1]) for tx in range(block[0])]
+                        for t in ts:
+                            t.start()
+                        for t in ts:
+                            t.join()
+                        if errors:
+                            raise errors[0]
+        return launch
+
+
+class _CudaEmu(types.ModuleType):
+    """The slice of numba.cuda the reference's kernels use, executed with Python threads."""
+
+    def __init__(self, name="numba.cuda"):
+        super().__init__(name)
+        import threading
+        self.__path__ = []
+        self._tls = threading.local()
+        emu = self
+
+        class _Local:
+            @staticmethod
+            def array(shape, dtype=np.float32):
+                return np.zeros(shape, dtype=dtype)
+
+        class _Shared:
+            @staticmethod
+            def array(shape, dtype=np.float32):
+                tls = emu._tls
+                key = tls.nshared                      # the n-th shared.array call of this thread: one array per block
+                tls.nshared += 1
+                with tls.state["lock"]:
+                    if key not in tls.state["shared"]:
+                        tls.state["shared"][key] = np.zeros(shape, dtype=dtype)
+                    return tls.state["shared"][key]
+        self.local, self.shared = _Local, _Shared
+
+    threadIdx = property(lambda self: self._tls.threadIdx)
+    blockIdx = property(lambda self: self._tls.blockIdx)
+    blockDim = property(lambda self: self._tls.blockDim)
+    gridDim = property(lambda self: self._tls.gridDim)
+
+    def syncthreads(self):
+        self._tls.state["barrier"].wait()
+
+    def jit(self, *args, **kwargs):
+        device = bool(kwargs.get("device", False))
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            return _CudaKernel(self, args[0])
+        return (lambda fn: fn) if device else (lambda fn: _CudaKernel(self, fn))
+
+    def to_device(self, ary, stream=None):
+        return _DevArray(ary)
+
+    def stream(self):
+        return _Stream()
+
+    def select_device(self, i):
+        return None
+
+    def synchronize(self):
+        return None
+
+
 class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def find_spec(self, fullname, path, target=None):
         if fullname.split(".")[0] in _STUB_ROOTS or fullname in _STUB_EXACT:
@@ -98,6 +237,8 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return None
 
     def create_module(self, spec):
+        if spec.name == "numba.cuda":
+            return _CudaEmu()
         mod = _Anything(spec.name)
         mod.__path__ = []
         return mod
