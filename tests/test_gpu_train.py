@@ -378,7 +378,7 @@ def test_decisions_tap_surface(pp, hip_lib):
     tr = pp.Trainer(cfg, w, max_batch=B, max_points_per_frame=4096)
     eng = tr.engine
     n = ctypes.c_int64(0)
-    assert eng._lib.pp_train_fetch_decisions(eng._h, 0, None, 0, ctypes.byref(n)) == 3      # PP_ERR_STATE: no step yet
+    assert eng._lib.pp_train_fetch_decisions(eng._h, 0, None, 0, ctypes.byref(n)) == 2      # PP_ERR_STATE: no step yet
     tr.forward_backward(frames, labels, reg)
     assert eng._lib.pp_train_fetch_decisions(eng._h, 0, None, 0, None) == 1                  # PP_ERR_ARG: count is NULL
     assert eng._lib.pp_train_fetch_decisions(eng._h, 99, None, 0, ctypes.byref(n)) == 1      # no such layer
