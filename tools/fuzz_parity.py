@@ -137,17 +137,28 @@ def one_case(pp, util_ref, seed):
             # then be there, and a box may only have moved past boxes whose score it shares to within twice this case's
             # measured head-map error (a logit error e moves a score by at most e / 4).
             dist = np.max(np.abs(rows_a[:, None, :] - rows_r[None, :, :]) / scale(rows_r)[None, :, :], axis=2) * TOL
-            perm = np.argmin(dist, axis=1)
-            if not (sorted(perm.tolist()) == list(range(k)) and np.all(dist[np.arange(k), perm] <= TOL)):
-                i = int(np.argmax(np.min(dist, axis=1)))
-                raise AssertionError(f"frame {b}: different boxes (worst row distance {float(np.max(np.min(dist, axis=1))):.3g}; "
-                                     f"row {i}: hip {np.array2string(rows_a[i], precision=6)} oracle "
-                                     f"{np.array2string(rows_r[perm[i]], precision=6)})")
+            tie = max(2e-6, 2 * worst)
             sc = r["scores"]
-            for i in range(k):
-                lo_, hi_ = min(i, perm[i]), max(i, perm[i])
-                assert float(np.max(sc[lo_:hi_ + 1]) - np.min(sc[lo_:hi_ + 1])) <= max(2e-6, 2 * worst), \
-                    f"frame {b}: box {i} moved to {perm[i]} across scores {sc[lo_:hi_ + 1]}"
+            # rows of one list without a partner in the other: accepted only at the CUT -- the selection keeps the best
+            # candidates (the reference: top-100 by np.argpartition; the kernel: ties broken by the lower anchor index), and
+            # when the last place is shared by equal scores the two implementations may keep different anchors.  Such rows
+            # must carry the lowest score of their list, and the same one (to the tie bound) in both lists.
+            a_un = [i for i in range(k) if dist[i].min() > TOL]
+            r_un = [j for j in range(k) if dist[:, j].min() > TOL]
+            if a_un or r_un:
+                smin = float(sc.min())
+                at_cut = all(abs(float(a["scores"][i]) - smin) <= tie for i in a_un) and all(abs(float(sc[j]) - smin) <= tie for j in r_un)
+                if not (at_cut and len(a_un) == len(r_un)):
+                    i = a_un[0] if a_un else int(np.argmin(dist[:, r_un[0]]))
+                    raise AssertionError(f"frame {b}: different boxes ({len(a_un)} hip rows / {len(r_un)} oracle rows without a partner; "
+                                         f"hip row {i}: {np.array2string(rows_a[i], precision=6)}; lowest oracle score {smin:.7f})")
+            keep_a = [i for i in range(k) if i not in a_un]
+            perm = {i: int(np.argmin(dist[i])) for i in keep_a}
+            assert len(set(perm.values())) == len(keep_a), f"frame {b}: two hip rows match one oracle row"
+            for i, j in perm.items():
+                lo_, hi_ = min(i, j), max(i, j)
+                assert float(np.max(sc[lo_:hi_ + 1]) - np.min(sc[lo_:hi_ + 1])) <= tie, \
+                    f"frame {b}: box {i} moved to {j} across scores {sc[lo_:hi_ + 1]}"
             ties += 1
         return f"B={B} grid={d.grid[0]}x{d.grid[1]}x{d.grid[2]} C={d.pfn_filters} f={d.num_filters} L={d.layer_nums} " \
                f"cls={d.num_class} dir={int(d.use_direction_classifier)} dets={ndet} maxerr={worst:.2e}" + (f" tie-order-frames={ties}" if ties else "")
