@@ -27,6 +27,7 @@
 extern "C" {
 #endif
 
+/* 3: PP_ERR_NUMERIC, pp_set_gemm_precision / pp_get_gemm_precision, pp_set_cache_budget.  4: pp_train_fetch_decisions. */
 #define PP_ABI_VERSION 4
 
 enum pp_status {
