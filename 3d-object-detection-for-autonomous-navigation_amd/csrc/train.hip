@@ -2075,10 +2075,19 @@ unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
 static void bn_finalize(const TrainCtx& cx, const float* part, int nparts, int C, float n_rows, const float* n_rows_dev,
                         float momentum, int unbiased, float* stats, float* mmean, float* mvar, int ntaps,
                         const float* gamma = nullptr, const float* beta = nullptr, float4* coef = nullptr) {
-    if ((long)nparts * ntaps >= 2048)
+    // lanes per channel by the number of (partial row, tap) pairs a channel has: a whole workgroup from 128 pairs on, a wave
+    // from 32 (PP_TRAIN_FIN_THR="a,b" for A/B measurements; round 4, the 20 launches of a step: thresholds 2048 / 512 ->
+    // 154 us at B=32 and 102 us at B=2; 512 / 128 -> 112 / 90; 128 / 32 -> 114 / 87: the launch is a chain of dependent
+    // load rounds, and more lanes per channel make it shorter even when most of them carry one pair)
+    static long thr256 = -1, thr64 = -1;
+    if (thr256 < 0) {
+        thr256 = 128; thr64 = 32;
+        if (const char* e = getenv("PP_TRAIN_FIN_THR")) { long a = 0, b = 0; if (sscanf(e, "%ld,%ld", &a, &b) == 2 && a > 0 && b > 0) { thr256 = a; thr64 = b; } }
+    }
+    if ((long)nparts * ntaps >= thr256)
         PP_LAUNCH("k_tr_bn_finalize", (k_tr_bn_finalize<256>), dim3(C), dim3(256), 0, cx.stream, part, nparts, C, n_rows,
                   n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps, gamma, beta, coef);
-    else if ((long)nparts * ntaps >= 512)
+    else if ((long)nparts * ntaps >= thr64)
         PP_LAUNCH("k_tr_bn_finalize", (k_tr_bn_finalize<64>), dim3((C + 3) / 4), dim3(256), 0, cx.stream, part, nparts, C, n_rows,
                   n_rows_dev, momentum, unbiased, stats, mmean, mvar, ntaps, gamma, beta, coef);
     else
