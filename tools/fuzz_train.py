@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 VERBOSE = False
 
 
-def one_case(pp, util_ref, train_ref, fuzz_parity, seed):
+def one_case(pp, util_ref, train_ref, fuzz_parity, seed, check_decisions=False):
     rng = np.random.default_rng(seed)
     B = int(rng.integers(1, 7))
     cfg = fuzz_parity.random_config(pp, rng, B)
@@ -94,6 +94,12 @@ def one_case(pp, util_ref, train_ref, fuzz_parity, seed):
         desc = (f"B={B} grid={d.nx}x{d.ny}x{d.nz} s1={s1} C={d.pfn_filters} f={d.num_filters} L={d.layer_nums} cls={d.num_class} "
                 f"dir={int(d.use_direction_classifier)} dist={int(d.with_distance)} T={d.max_points} worst={worst[1]:.2e} ({worst[0]}) "
                 f"fwd={fwd_worst[1]:.1e} ({fwd_worst[0]})")
+        if check_decisions:      # always hold the case to the float64 graph that takes the step's own ReLU / max decisions
+            _, g64d, _, _ = train_ref.training_step(d, w, ex, labels, reg, ex[6][0], dtype=__import__("torch").float64,
+                                                    forced=util_ref.forced_decisions(tr, ex))
+            ed = max(float(np.abs(got[k] - g64d[k]).max()) / max(float(np.abs(g64d[k]).max()), 1e-12) for k in g64d)
+            desc += f" | float64 with the step's decisions: {ed:.2e}"
+            assert ed <= 1e-4, desc
         if worst[1] > 1e-4:
             # The same graph in float64 is the yardstick.  Two legitimate reasons for a float32 implementation to be off:
             # (1) the problem's float32 conditioning (torch's own float32 autograd is then as far from float64): the kernels
