@@ -828,8 +828,9 @@ def test_fuzz_train_seeds(pp, hip_lib, seed):
     """A few cases of the randomised training-step soak (round 4: 1 026 cases in both forward modes, none unexplained):
     losses, every gradient against torch autograd, a bit-identical second pass.  Seeds 5212 and 5120 are the documented
     hard kind: a pre-ReLU value of 1e-7 (float64) in one layer, so the gradients agree with the plain float32 / float64
-    graphs only if the kernels' round-off happens to put that element on the same side (it did not with the round's first
-    kernels, it does since the BatchNorm finalise adds its partial rows in another order).  Whatever the side, every case
+    graphs only if the kernels' round-off happens to put that element on the same side (with the round's first kernels
+    neither did: 2.9e-2 / 8.1e-2 off; since the BatchNorm finalise adds its partial rows in another order 5212 does,
+    5120 still does not).  Whatever the side, every case
     here must agree to 1e-4 with the float64 graph that takes the step's OWN ReLU / max decisions
     (pp_train_fetch_decisions) -- the soak's criterion for such cases, applied to all six."""
     from oracle import train_ref
